@@ -1,0 +1,142 @@
+"""ORACLE (test infrastructure, NOT the product): ctypes binding + iteration loop around
+oracle/align_ref.c (see that file's header for the reference lines it follows).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Cfg(C.Structure):
+    _fields_ = [("E", C.c_int), ("N", C.c_int), ("P", C.c_int), ("use_mono", C.c_int),
+                ("norm_pw_scale", C.c_int), ("dist_l2", C.c_int), ("train_poses", C.c_int),
+                ("train_focals", C.c_int), ("train_pp", C.c_int), ("base_scale", C.c_float),
+                ("pw_break", C.c_float), ("focal_break", C.c_float), ("total_area_i", C.c_double),
+                ("total_area_j", C.c_double)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libalign_ref.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.a3r_oracle_num_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def cosine_schedule(t, lr_start, lr_end):   # commons.py:123-125
+    return lr_end + (lr_start - lr_end) * (1 + np.cos(t * np.pi)) / 2
+
+
+def linear_schedule(t, lr_start, lr_end):   # commons.py:128-130
+    return lr_start + (lr_end - lr_start) * t
+
+
+class AlignOracle:
+    """State + loop of PointCloudOptimizer (optimizer.py:22-71, base_opt.py:424-464), all-numpy/C."""
+
+    def __init__(self, ei, ej, pred_i, pred_j, w_i, w_j, imshapes, mono=None, base_scale=0.5, pw_break=20.0,
+                 focal_break=20.0, norm_pw_scale=True, dist="l1", train_poses=True, train_focals=True,
+                 train_pp=False):
+        E, P = w_i.shape
+        N = len(imshapes)
+        self.E, self.N, self.P = E, N, P
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        self.ei = np.ascontiguousarray(ei, dtype=np.int32)
+        self.ej = np.ascontiguousarray(ej, dtype=np.int32)
+        self.pred_i, self.pred_j = f32(pred_i).reshape(E, P, 3), f32(pred_j).reshape(E, P, 3)
+        self.w_i, self.w_j = f32(w_i), f32(w_j)
+        self.imw = np.asarray([w for h, w in imshapes], dtype=np.int32)
+        self.imarea = np.asarray([h * w for h, w in imshapes], dtype=np.int32)
+        self.pp0 = f32([(w / 2, h / 2) for h, w in imshapes])
+        self.mono = None if mono is None else f32(mono).reshape(N, P)
+        self.cfg = Cfg(E, N, P, int(mono is not None), int(norm_pw_scale), int(dist == "l2"), int(train_poses),
+                       int(train_focals), int(train_pp), base_scale, pw_break, focal_break,
+                       float(sum(int(self.imarea[i]) for i in self.ei)), float(sum(int(self.imarea[j]) for j in self.ej)))
+        self.params = {}
+        self.adam = {}
+        self.step_count = 0
+
+    def set_params(self, pw_poses, depth, im_poses, im_focals, shifts=None, im_pp=None, pw_adaptors=None):
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).copy()
+        self.params = dict(pw_poses=f32(pw_poses).reshape(self.E, 8), depth=f32(depth).reshape(self.N, self.P),
+                           im_poses=f32(im_poses).reshape(self.N, 7), im_focals=f32(im_focals).reshape(self.N),
+                           shifts=f32(shifts if shifts is not None else np.zeros(self.N)).reshape(self.N),
+                           im_pp=f32(im_pp if im_pp is not None else np.zeros((self.N, 2))).reshape(self.N, 2),
+                           pw_adaptors=f32(pw_adaptors if pw_adaptors is not None else np.zeros((self.E, 2))))
+        self.adam = {}
+        self.step_count = 0
+
+    def trainable(self):
+        t = ["pw_poses", "depth"]
+        if self.cfg.use_mono:
+            t.append("shifts")
+        if self.cfg.train_poses:
+            t.append("im_poses")
+        if self.cfg.train_focals:
+            t.append("im_focals")
+        if self.cfg.train_pp:
+            t.append("im_pp")
+        return t
+
+    def loss_grad(self):
+        p = self.params
+        g = {k: np.zeros_like(p[k]) for k in self.trainable()}
+        loss = C.c_double(0)
+        lib().a3r_oracle_align_loss_grad(
+            C.byref(self.cfg), _p(self.ei, C.c_int), _p(self.ej, C.c_int), _p(self.imw, C.c_int),
+            _p(self.imarea, C.c_int), _p(self.pred_i), _p(self.pred_j), _p(self.w_i), _p(self.w_j), _p(self.mono),
+            _p(self.pp0), _p(p["pw_poses"]), _p(p["pw_adaptors"]), _p(p["depth"]), _p(p["shifts"]), _p(p["im_poses"]),
+            _p(p["im_focals"]), _p(p["im_pp"]), C.byref(loss), _p(g.get("pw_poses")), _p(g.get("depth")),
+            _p(g.get("shifts")), _p(g.get("im_poses")), _p(g.get("im_focals")), _p(g.get("im_pp")))
+        return loss.value, g
+
+    def step(self, lr, b1=0.9, b2=0.9, eps=1e-8):
+        loss, g = self.loss_grad()
+        self.step_count += 1
+        for k, gk in g.items():
+            if k not in self.adam:
+                self.adam[k] = (np.zeros_like(gk), np.zeros_like(gk))
+            m, v = self.adam[k]
+            lib().a3r_oracle_adam(_p(self.params[k]), _p(gk), _p(m), _p(v), C.c_long(gk.size), C.c_float(lr),
+                                  C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_int(self.step_count))
+        return loss
+
+    def run(self, niter, lr, schedule="cosine", lr_min=1e-6, first_iter=0, total_iters=None):
+        """global_alignment_loop base_opt.py:424-447."""
+        total = total_iters or niter
+        losses = []
+        for it in range(first_iter, first_iter + niter):
+            t = it / total
+            cur = cosine_schedule(t, lr, lr_min) if schedule == "cosine" else linear_schedule(t, lr, lr_min)
+            losses.append(self.step(float(cur)))
+        return losses
+
+    def pose_matrices(self):
+        p = self.params
+        eM = np.zeros((self.E, 3, 4), np.float32)
+        iR = np.zeros((self.N, 3, 4), np.float32)
+        f = np.zeros(self.N, np.float32)
+        pp = np.zeros((self.N, 2), np.float32)
+        lib().a3r_oracle_pose_matrices(C.byref(self.cfg), _p(p["pw_poses"]), _p(p["pw_adaptors"]), _p(p["im_poses"]),
+                                       _p(p["im_focals"]), _p(p["im_pp"]), _p(self.pp0), _p(eM), _p(iR), _p(f), _p(pp))
+        return eM, iR, f, pp

@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build container.
+
+Usage (build container only -- /root/reference does not exist on the GPU box):
+    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align] [--out tests/golden]
+
+What it does
+  * puts /root/reference on sys.path (read-only, bytecode writing disabled) and imports the
+    reference's own dust3r.model / dust3r.inference / dust3r.image_pairs / dust3r.cloud_opt;
+  * drives it with inputs and weights from the build's deterministic generators
+    (align3r_amd.weights.hash_uniform / synthetic_state_dict), so every fixture can be
+    regenerated bit-for-bit and the same inputs can be rebuilt on the GPU box without torch RNG;
+  * writes only DATA (inputs that are not regenerable + expected outputs) as .npz/.json.
+
+Harness-side patches (nothing in the reference tree is modified):
+  * ``torch.nn.Module.cuda`` -> identity: the reference model constructor calls .cuda()
+    (dust3r/model.py:96) and this container has no GPU;
+  * import stubs for third-party packages that are not installed here and are not on the
+    hot path: wandb, cv2, torchvision, evo (dust3r/cloud_opt/__init__.py:11, utils/image.py:12-14,
+    utils/vo_eval.py:6-13);
+  * ``roma`` (unpinned dependency, requirements.txt:3, not installed, cannot be fetched): a
+    stand-in providing ONLY the closed-form unit-quaternion(XYZW)->4x4 used by the inner loop
+    (base_opt.py:188).  The fixtures' metadata records this.  Everything else in the aligner
+    iteration -- forward, autograd, Adam, schedules -- is the reference's own code.
+    The MST/PnP initialisation (init_im_poses.py) needs roma's SVD registration and cv2's
+    RANSAC-PnP and is therefore NOT exercised: goldens start from a captured parameter state.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+
+import numpy as np
+import torch
+
+from align3r_amd.weights import (TINY, VITL, hash_uniform, param_spec, reference_aliases,
+                                 synthetic_state_dict)
+
+
+# ----------------------------------------------------------------------------- reference import
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+
+    def _ga(attr):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        return _stub(f"{name}.{attr}")
+    m.__getattr__ = _ga
+    m.__path__ = []
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _install_roma_standin():
+    roma = types.ModuleType("roma")
+
+    def unitquat_to_rotmat(q):
+        x, y, z, w = q.unbind(-1)
+        tx, ty, tz = 2 * x, 2 * y, 2 * z
+        twx, twy, twz = tx * w, ty * w, tz * w
+        txx, txy, txz = tx * x, ty * x, tz * x
+        tyy, tyz, tzz = ty * y, tz * y, tz * z
+        rows = [1 - (tyy + tzz), txy - twz, txz + twy,
+                txy + twz, 1 - (txx + tzz), tyz - twx,
+                txz - twy, tyz + twx, 1 - (txx + tyy)]
+        return torch.stack(rows, -1).reshape(q.shape[:-1] + (3, 3))
+
+    class RigidUnitQuat:
+        def __init__(self, linear, translation):
+            self.linear, self.translation = linear, translation
+
+        def normalize(self):
+            return RigidUnitQuat(self.linear / torch.norm(self.linear, dim=-1, keepdim=True), self.translation)
+
+        def to_homogeneous(self):
+            R = unitquat_to_rotmat(self.linear)
+            top = torch.cat((R, self.translation[..., None]), -1)
+            bottom = torch.zeros_like(top[..., :1, :])
+            bottom[..., 0, 3] = 1
+            return torch.cat((top, bottom), -2)
+
+    roma.RigidUnitQuat = RigidUnitQuat
+    roma.unitquat_to_rotmat = unitquat_to_rotmat
+    sys.modules["roma"] = roma
+
+
+def import_reference(aligner=False):
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    torch.nn.Module.cuda = lambda self, device=None: self
+    if aligner:
+        wt = _stub("wandb.wandb_torch", torch=torch)
+        _stub("wandb", wandb_torch=wt)
+        _stub("cv2")
+        ident = lambda *a, **k: (lambda x: x)
+        tvf = _stub("torchvision.transforms", Compose=ident, ToTensor=ident, Normalize=ident)
+        _stub("torchvision", transforms=tvf)
+        for n in ("evo", "evo.main_ape", "evo.main_rpe", "evo.core", "evo.core.sync", "evo.core.metrics",
+                  "evo.core.trajectory", "evo.tools", "evo.tools.file_interface", "evo.tools.plot"):
+            _stub(n)
+        _install_roma_standin()
+
+
+def ref_model(cfg, img_size=(512, 512)):
+    from dust3r.model import AsymmetricCroCo3DStereo, inf  # noqa
+    m = AsymmetricCroCo3DStereo(pos_embed=f"RoPE{int(cfg.rope_base)}", patch_embed_cls="PatchEmbedDust3R",
+                                img_size=img_size, head_type="dpt", output_mode="pts3d",
+                                depth_mode=("exp", -inf, inf), conf_mode=("exp", 1, inf),
+                                enc_embed_dim=cfg.enc_embed_dim, enc_depth=cfg.enc_depth,
+                                enc_num_heads=cfg.enc_num_heads, dec_embed_dim=cfg.dec_embed_dim,
+                                dec_depth=cfg.dec_depth, dec_num_heads=cfg.dec_num_heads, landscape_only=False)
+    spec = {n: s for n, s, _ in param_spec(cfg)}
+    spec.update({a: spec[c] for a, c in reference_aliases(cfg).items()})
+    ref_sd = m.state_dict()
+    assert set(ref_sd) == set(spec), (set(ref_sd) ^ set(spec))
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+    sd = synthetic_state_dict(cfg, seed=0, with_aliases=True)
+    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return m.eval()
+
+
+# ----------------------------------------------------------------------------- shared input builders
+def make_views(n_frames, H, W, seed=1):
+    """Synthetic frames: img ~ U(-1,1) [1,3,H,W], pred_depth ~ U(0,1) [1,H,W,3] (hash generator)."""
+    views = []
+    for i in range(n_frames):
+        img = (2.0 * hash_uniform(f"img{i}", 3 * H * W, seed)).astype(np.float32).reshape(1, 3, H, W)
+        pd = (hash_uniform(f"pred_depth{i}", H * W * 3, seed) + 0.5).astype(np.float32).reshape(1, H, W, 3)
+        views.append(dict(img=torch.from_numpy(img), pred_depth=torch.from_numpy(pd),
+                          true_shape=torch.tensor([[H, W]], dtype=torch.int32), idx=i, instance=str(i)))
+    return views
+
+
+def stats(a):
+    a = np.asarray(a, dtype=np.float64)
+    return dict(mean=float(a.mean()), std=float(a.std()), absmax=float(np.abs(a).max()), sum=float(a.sum()))
+
+
+# ----------------------------------------------------------------------------- fixtures
+def gen_pairs(out):
+    """make_pairs known answers (dust3r/image_pairs.py:11-75)."""
+    from dust3r.image_pairs import make_pairs
+    import contextlib, io
+    cases = [(2, "complete"), (16, "complete"), (16, "swin-3-noncyclic"), (16, "swinstride-5-noncyclic"),
+             (16, "swin2stride-5-noncyclic"), (16, "swin-5"), (16, "swin-3"), (16, "logwin-3"),
+             (16, "logwin-4-noncyclic"), (16, "oneref-0"), (16, "oneref-5"), (7, "swin-3"), (64, "complete"),
+             (128, "swinstride-5-noncyclic"), (256, "swin2stride-5-noncyclic"), (50, "swin-5-noncyclic"),
+             (1, "complete"), (3, "swin-10")]
+    res = []
+    for n, sg in cases:
+        for sym in (True, False):
+            for pref in (None, "seq3", "cyc2"):
+                if pref and n > 64:
+                    continue
+                imgs = [dict(idx=i) for i in range(n)]
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        pairs = make_pairs(imgs, scene_graph=sg, prefilter=pref, symmetrize=sym)
+                except ValueError:   # reference raises on an empty edge list + prefilter (image_pairs.py:89)
+                    res.append(dict(n=n, scene_graph=sg, symmetrize=sym, prefilter=pref, error="ValueError"))
+                    continue
+                e = [(a["idx"], b["idx"]) for a, b in pairs]
+                h = hashlib.sha256(repr(e).encode()).hexdigest()[:16]
+                rec = dict(n=n, scene_graph=sg, symmetrize=sym, prefilter=pref, n_edges=len(e), sha=h)
+                if len(e) <= 200:
+                    rec["edges"] = e
+                res.append(rec)
+    with open(os.path.join(out, "pairs.json"), "w") as f:
+        json.dump(dict(python=sys.version.split()[0], cases=res), f)
+    print("pairs:", len(res), "cases")
+
+
+def gen_ops(out):
+    """Op-level goldens from the reference's own modules (TINY-sized weights, real head_dim 64)."""
+    import dust3r.utils.path_to_croco  # noqa: F401  (puts /root/reference/croco on sys.path)
+    from models.pos_embed import RoPE2D
+    from models.blocks import Block, DecoderBlock
+    import torch.nn as nn
+    from functools import partial
+    g = {}
+    # RoPE2D fallback (pos_embed.py:110-157)
+    B, H, N = 2, 3, 20
+    tok = (4 * hash_uniform("rope_tok", B * H * N * 64, 3)).astype(np.float32).reshape(B, H, N, 64)
+    pos = (np.abs(hash_uniform("rope_pos", B * N * 2, 3)) * 2 * 31.99).astype(np.int64).reshape(B, N, 2)
+    rope = RoPE2D(freq=100.0)
+    g["rope_tok"], g["rope_pos"] = tok, pos
+    g["rope_out"] = rope(torch.from_numpy(tok), torch.from_numpy(pos)).numpy()
+    # Block / DecoderBlock (blocks.py:114-191) at D=128, 2 heads
+    D, Hh = 128, 2
+    norm = partial(nn.LayerNorm, eps=1e-6)
+    blk = Block(D, Hh, 4, qkv_bias=True, norm_layer=norm, rope=rope).eval()
+    dblk = DecoderBlock(D, Hh, mlp_ratio=4, qkv_bias=True, norm_layer=norm, norm_mem=True, rope=rope).eval()
+    from align3r_amd.weights import _block_spec, synthetic_tensor
+    for mod, pre, cross in ((blk, "opblk", False), (dblk, "opdblk", True)):
+        sd = {n[len(pre) + 1:]: torch.from_numpy(synthetic_tensor(n, s, k, 5)) for n, s, k in _block_spec(pre, D, 4 * D, cross)}
+        mod.load_state_dict(sd, strict=True)
+    h, w = 3, 5
+    x = (2 * hash_uniform("blk_x", 2 * h * w * D, 3)).astype(np.float32).reshape(2, h * w, D)
+    y = (2 * hash_uniform("blk_y", 2 * h * w * D, 3)).astype(np.float32).reshape(2, h * w, D)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    p = np.broadcast_to(np.stack([yy.ravel(), xx.ravel()], -1)[None], (2, h * w, 2)).astype(np.int64).copy()
+    with torch.no_grad():
+        g["blk_x"], g["blk_y"], g["blk_pos"] = x, y, p
+        g["blk_out"] = blk(torch.from_numpy(x), torch.from_numpy(p)).numpy()
+        g["dblk_out"] = dblk(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), torch.from_numpy(p))[0].numpy()
+    # bilinear x2 align_corners=True and postprocess
+    from models.dpt_block import Interpolate
+    from dust3r.heads.postprocess import postprocess
+    inf = float("inf")
+    u = (2 * hash_uniform("up_x", 2 * 7 * 5 * 6, 3)).astype(np.float32).reshape(2, 6, 7, 5)  # NCHW
+    g["up_x"] = u
+    g["up_out"] = Interpolate(2, "bilinear", True)(torch.from_numpy(u)).numpy()
+    f = (6 * hash_uniform("pp_x", 2 * 4 * 9 * 11, 3)).astype(np.float32).reshape(2, 4, 9, 11)
+    f[0, :3, 0, 0] = 0.0           # exercise the d.clip(min=1e-8) branch
+    r = postprocess(torch.from_numpy(f), 0, ("exp", -inf, inf), ("exp", 1, inf))
+    g["pp_x"], g["pp_pts3d"], g["pp_conf"] = f, r["pts3d"].numpy(), r["conf"].numpy()
+    np.savez_compressed(os.path.join(out, "ops.npz"), **g)
+    print("ops:", {k: v.shape for k, v in g.items()})
+
+
+def _run_inference(model, views, pairs_idx):
+    from dust3r.inference import inference
+    pairs = [(views[i], views[j]) for i, j in pairs_idx]
+    with torch.no_grad():
+        return inference(pairs, model, "cpu", batch_size=1, verbose=False)
+
+
+def gen_tiny(out):
+    """End-to-end TINY model, full tensors + intermediates, two resolutions (one with an odd token grid
+    so that the refinenet4 crop dpt_head.py:57 matters)."""
+    model = ref_model(TINY, img_size=(512, 512))
+    g = {}
+    for tag, (H, W) in (("a", (64, 96)), ("b", (48, 80))):
+        views = make_views(2, H, W, seed=1)
+        r = _run_inference(model, views, [(1, 0), (0, 1)])
+        g[f"{tag}_pts3d_1"] = r["pred1"]["pts3d"].numpy()
+        g[f"{tag}_conf_1"] = r["pred1"]["conf"].numpy()
+        g[f"{tag}_pts3d_2"] = r["pred2"]["pts3d_in_other_view"].numpy()
+        g[f"{tag}_conf_2"] = r["pred2"]["conf"].numpy()
+        # intermediates for the first pair (1,0)
+        v1, v2 = views[1], views[0]
+        with torch.no_grad():
+            (s1, s2), (f1, f2), (p1, p2) = model._encode_symmetrized(v1, v2)
+            pc = torch.cat((v1["pred_depth"].permute(0, 3, 1, 2), v2["pred_depth"].permute(0, 3, 1, 2)), 0)
+            pct, pcp = model.patch_embed_point_cloud(pc, true_shape=torch.cat((s1, s2), 0))
+            dec1, dec2 = model._decoder(f1, p1, f2, p2, pct, pcp)
+            dec1, dec2 = list(dec1), list(dec2)
+            raw1, _ = model.downstream_head1.dpt([t.float() for t in dec1], image_size=(H, W))
+        g[f"{tag}_enc1"] = f1.numpy()
+        g[f"{tag}_pc_tokens"] = pct.numpy()
+        g[f"{tag}_dec1_6"] = dec1[6].numpy()
+        g[f"{tag}_dec1_last"] = dec1[-1].numpy()
+        g[f"{tag}_dec2_last"] = dec2[-1].numpy()
+        g[f"{tag}_raw1"] = raw1.permute(0, 2, 3, 1).numpy()
+    np.savez_compressed(os.path.join(out, "tiny_e2e.npz"), **g)
+    print("tiny:", {k: v.shape for k, v in g.items()})
+
+
+def gen_vitl(out):
+    """BASELINE config 1: 2 frames 224x224, ViT-L, pairs [(1,0),(0,1)], inference(bs=1) on CPU.
+    Stored: stride-4 sub-sampled maps + full-tensor statistics."""
+    model = ref_model(VITL, img_size=(512, 512))
+    H = W = 224
+    views = make_views(2, H, W, seed=1)
+    r = _run_inference(model, views, [(1, 0), (0, 1)])
+    g, meta = {}, {}
+    for name, t in (("pts3d_1", r["pred1"]["pts3d"]), ("conf_1", r["pred1"]["conf"]),
+                    ("pts3d_2", r["pred2"]["pts3d_in_other_view"]), ("conf_2", r["pred2"]["conf"])):
+        a = t.numpy()
+        g[name] = a[:, ::4, ::4].copy()
+        meta[name] = stats(a)
+    np.savez_compressed(os.path.join(out, "vitl_cfg1.npz"), **g)
+    with open(os.path.join(out, "vitl_cfg1.json"), "w") as f:
+        json.dump(dict(H=H, W=W, pairs=[(1, 0), (0, 1)], stride=4, stats=meta), f, indent=1)
+    print("vitl:", meta)
+
+
+def _align_scene(kind, N, H, W, seed):
+    """Synthetic inference output for the aligner. kind 'random': preds ~ N(0,1);
+    kind 'geom': a bumpy surface seen by N cameras on a small arc, preds = true points in
+    camera-i frame + 1% noise, so the optimisation has a consistent solution."""
+    edges = [(i, j) for i in range(N) for j in range(N) if i != j]
+    rng = np.random.default_rng(seed)
+    E = len(edges)
+    if kind == "random":
+        p1 = rng.standard_normal((E, H, W, 3)).astype(np.float32)
+        p2 = rng.standard_normal((E, H, W, 3)).astype(np.float32)
+    else:
+        f = 1.2 * max(H, W)
+        u, v = np.meshgrid(np.arange(W) - W / 2 + 0.5, np.arange(H) - H / 2 + 0.5)
+        cams = []
+        for n in range(N):
+            a = 0.15 * (n - (N - 1) / 2)
+            R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+            t = np.array([0.6 * np.sin(a) * 3, 0.05 * n, 3 - 3 * np.cos(a)])
+            cams.append((R, t))
+        world = []
+        for n in range(N):
+            d = 3 + 0.5 * np.sin(u / W * 6 + n) * np.cos(v / H * 4) + 0.2 * rng.random((H, W))
+            pc = np.stack([u / f * d, v / f * d, d], -1)
+            R, t = cams[n]
+            world.append(pc @ R.T + t)
+        p1 = np.empty((E, H, W, 3), np.float32)
+        p2 = np.empty((E, H, W, 3), np.float32)
+        for e, (i, j) in enumerate(edges):
+            R, t = cams[i]
+            p1[e] = (world[i] - t) @ R + 0.01 * rng.standard_normal((H, W, 3))
+            p2[e] = (world[j] - t) @ R + 0.01 * rng.standard_normal((H, W, 3))
+    c1 = (1 + 9 * rng.random((E, H, W))).astype(np.float32)
+    c2 = (1 + 9 * rng.random((E, H, W))).astype(np.float32)
+    mono = [(0.5 + 3 * rng.random((H, W))).astype(np.float32) for _ in range(N)]
+    return edges, p1, p2, c1, c2, mono
+
+
+def gen_align(out):
+    """PointCloudOptimizer inner loop: captured initial state, autograd gradients of the first
+    iteration, and parameter state/loss after k in {1,5,50} global_alignment_iter steps."""
+    from dust3r.cloud_opt import global_aligner, GlobalAlignerMode
+    from dust3r.cloud_opt.base_opt import global_alignment_iter
+    meta = dict(note="roma stand-in: closed-form XYZW unit-quaternion -> 4x4 (see module docstring)", cases=[])
+    g = {}
+    cases = [("rand_nomono_cos", "random", 4, 16, 24, False, "cosine", 0.05),
+             ("geom_nomono_cos", "geom", 5, 24, 32, False, "cosine", 0.05),
+             ("geom_mono_lin", "geom", 5, 24, 32, True, "linear", 0.01),
+             ("rand_mono_cos", "random", 3, 16, 16, True, "cosine", 0.05)]
+    for tag, kind, N, H, W, use_mono, sched, lr in cases:
+        edges, p1, p2, c1, c2, mono = _align_scene(kind, N, H, W, seed=7)
+        E = len(edges)
+        view1 = dict(idx=[i for i, j in edges], true_shape=torch.tensor([[H, W]] * E))
+        view2 = dict(idx=[j for i, j in edges], true_shape=torch.tensor([[H, W]] * E))
+        pred1 = dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c1))
+        pred2 = dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c2))
+        output = dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2)
+        torch.manual_seed(11)
+        monos = [torch.from_numpy(m) for m in mono] if use_mono else []
+        net = global_aligner(output, use_mono, monos, "cpu", mode=GlobalAlignerMode.PointCloudOptimizer,
+                             verbose=False, min_conf_thr=3)
+        if use_mono:   # zeros would make the first steps degenerate; start from a small random state
+            with torch.no_grad():
+                net.scalemaps.copy_(0.1 * torch.randn_like(net.scalemaps))
+                net.shifts.copy_(0.05 * torch.randn_like(net.shifts))
+        for k in ("p1", "p2", "c1", "c2"):
+            g[f"{tag}_{k}"] = dict(p1=p1, p2=p2, c1=c1, c2=c2)[k]
+        if use_mono:
+            g[f"{tag}_mono"] = np.stack(mono)
+        trainable = [n for n, p in net.named_parameters() if p.requires_grad]
+        init = {n: p.detach().clone() for n, p in net.named_parameters() if n in trainable or n in ("im_pp", "pw_adaptors")}
+        for n, p in init.items():
+            g[f"{tag}_init_{n}"] = p.numpy()
+        # derived quantities pinning the pose parameterisation
+        with torch.no_grad():
+            g[f"{tag}_pw_poses_4x4"] = net.get_pw_poses().numpy()
+            g[f"{tag}_im_poses_4x4"] = net.get_im_poses().numpy()
+            g[f"{tag}_focals"] = net.get_focals().numpy()
+            g[f"{tag}_depth0"] = torch.stack(list(net.get_depthmaps(raw=True))).numpy() if use_mono else net.get_depthmaps(raw=True).numpy()
+            g[f"{tag}_pts3d0"] = net.get_pts3d(raw=True).numpy()
+        # gradient of the first forward
+        loss0 = net()
+        loss0.backward()
+        g[f"{tag}_loss0"] = np.float64(loss0.item())
+        for n, p in net.named_parameters():
+            if n in trainable:
+                g[f"{tag}_grad_{n}"] = p.grad.numpy().copy()
+                p.grad = None
+        # optimisation trajectory
+        niter = 50
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.9))
+        losses = []
+        for it in range(niter):
+            loss, cur_lr = global_alignment_iter(net, it, niter, lr, 1e-6, opt, sched)
+            losses.append(loss)
+            if it + 1 in (1, 5, 50):
+                for n, p in net.named_parameters():
+                    if n in trainable:
+                        g[f"{tag}_k{it+1}_{n}"] = p.detach().numpy().copy()
+        g[f"{tag}_losses"] = np.asarray(losses, np.float64)
+        meta["cases"].append(dict(tag=tag, kind=kind, N=N, H=H, W=W, use_mono=use_mono, schedule=sched, lr=lr,
+                                  lr_min=1e-6, niter=niter, edges=edges, trainable=trainable,
+                                  total_area_i=int(net.total_area_i), total_area_j=int(net.total_area_j)))
+        print("align", tag, "loss0", float(loss0), "->", losses[-1])
+    np.savez_compressed(os.path.join(out, "align.npz"), **g)
+    with open(os.path.join(out, "align.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=HERE)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    todo = [a.only] if a.only else ["pairs", "ops", "tiny", "vitl", "align"]
+    import_reference(aligner="align" in todo)
+    for t in todo:
+        globals()[f"gen_{t}"](a.out)
+
+
+if __name__ == "__main__":
+    main()
