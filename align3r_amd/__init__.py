@@ -1,0 +1,14 @@
+"""align3r_amd: MI355X-native pair-forward + global-alignment engine behind Align3R's Python API."""
+import importlib
+import sys
+
+__version__ = "0.1.0"
+
+_MIRRORED = ["dust3r", "dust3r.model", "dust3r.inference", "dust3r.image_pairs", "dust3r.cloud_opt",
+             "dust3r.cloud_opt.optimizer", "dust3r.cloud_opt.commons", "dust3r.utils", "dust3r.utils.device"]
+
+
+def install_as_dust3r():
+    """Make ``import dust3r.inference`` etc. resolve to this package's mirror modules."""
+    for name in _MIRRORED:
+        sys.modules[name] = importlib.import_module("align3r_amd." + name)

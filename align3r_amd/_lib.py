@@ -1,0 +1,117 @@
+"""ctypes binding of liba3r.so (C ABI declared in include/a3r.h).
+
+The library is the product's only compute path.  There is NO fallback: if the shared object is
+missing or a symbol cannot be resolved, importing/using the engine raises -- a GPU box that silently
+ran PyTorch eager instead of the HIP kernels would void every parity and performance claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liba3r.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_void = C.c_void_p
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("epi", C.c_int), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("relu_a", C.c_int),
+                ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
+                ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int)]
+
+
+class ModelConfigC(C.Structure):
+    _fields_ = [("enc_embed_dim", C.c_int), ("enc_depth", C.c_int), ("enc_num_heads", C.c_int),
+                ("dec_embed_dim", C.c_int), ("dec_depth", C.c_int), ("dec_num_heads", C.c_int),
+                ("mlp_ratio", C.c_int), ("patch_size", C.c_int), ("rope_base", C.c_float),
+                ("feature_dim", C.c_int), ("last_dim", C.c_int), ("layer_dims", C.c_int * 4)]
+
+
+class AlignDesc(C.Structure):
+    _fields_ = [("E", C.c_int), ("N", C.c_int), ("P", C.c_int), ("use_mono", C.c_int), ("norm_pw_scale", C.c_int),
+                ("dist_l2", C.c_int), ("train_poses", C.c_int), ("train_focals", C.c_int), ("train_pp", C.c_int),
+                ("base_scale", C.c_float), ("pw_break", C.c_float), ("focal_break", C.c_float),
+                ("total_area_i", C.c_double), ("total_area_j", C.c_double),
+                ("ei_host", c_void), ("ej_host", c_void), ("imw_host", c_void), ("imarea_host", c_void),
+                ("pred_i", c_void), ("pred_j", c_void), ("w_i", c_void), ("w_j", c_void), ("mono", c_void),
+                ("pp0", c_void), ("pw_poses", c_void), ("pw_adaptors", c_void), ("depth", c_void),
+                ("shifts", c_void), ("im_poses", c_void), ("im_focals", c_void), ("im_pp", c_void),
+                ("adam_pw_poses", c_void), ("adam_depth", c_void), ("adam_small", c_void),
+                ("workspace", c_void), ("workspace_bytes", C.c_size_t), ("loss_history", c_void),
+                ("loss_capacity", C.c_int)]
+
+
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_RELU, EPI_ROPE, EPI_RESID2, EPI_PIXSHUF = range(7)
+
+# name -> (restype, argtypes); every symbol declared in include/a3r.h
+SIGNATURES = {
+    "a3r_last_error": (C.c_char_p, []),
+    "a3r_version": (C.c_int, []),
+    "a3r_device_count": (C.c_int, []),
+    "a3r_rope2d": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_void]),
+    "a3r_layernorm": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
+    "a3r_linear": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
+    "a3r_conv3x3": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
+    "a3r_pack_conv3x3": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void]),
+    "a3r_pack_convT": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_attention": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_rope_table_host": (C.c_int, [c_void, c_void, C.c_int, C.c_float]),
+    "a3r_patchify": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, c_void]),
+    "a3r_upsample2x": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_head_final": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_long, C.c_int, c_void]),
+    "a3r_model_create": (C.c_int, [C.POINTER(ModelConfigC), C.POINTER(c_void)]),
+    "a3r_model_destroy": (C.c_int, [c_void]),
+    "a3r_model_set_weight": (C.c_int, [c_void, C.c_char_p, c_void, C.c_int, C.POINTER(C.c_int64)]),
+    "a3r_model_packed_bytes": (C.c_size_t, [c_void]),
+    "a3r_model_finalize": (C.c_int, [c_void, c_void, C.c_size_t, c_void]),
+    "a3r_model_workspace_bytes": (C.c_size_t, [c_void, C.c_int, C.c_int, C.c_int]),
+    "a3r_model_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
+    "a3r_model_tap": (C.c_int, [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_size_t)]),
+    "a3r_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "a3r_align_create": (C.c_int, [C.POINTER(AlignDesc), C.POINTER(c_void), c_void]),
+    "a3r_align_destroy": (C.c_int, [c_void]),
+    "a3r_align_step": (C.c_int, [c_void, C.c_float, c_void]),
+    "a3r_align_loss": (C.c_int, [c_void, c_void, c_void]),
+    "a3r_align_grad": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
+    "a3r_align_steps_done": (C.c_int, [c_void]),
+    "a3r_align_invalidate": (C.c_int, [c_void]),
+    "a3r_align_pose_matrices": (C.c_int, [c_void, c_void, c_void, c_void]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liba3r.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"liba3r.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `make -C align3r_amd/csrc` (there is no CPU/PyTorch fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    """Non-zero return code -> RuntimeError with the library's message (mirrors TORCH_CHECK)."""
+    if rc != 0:
+        msg = load().a3r_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what + ': ' if what else ''}{msg} (code {rc})")
+
+
+def ptr(t):
+    """data pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,636 @@
+// Global-alignment inner loop for gfx950: fused loss + analytic gradients + Adam.
+//
+// Replaces one global_alignment_iter of the reference (dust3r/cloud_opt/base_opt.py:450-464):
+//   loss = PointCloudOptimizer.forward()   dust3r/cloud_opt/optimizer.py:223-241
+//   loss.backward()                        (autograd in the reference; hand-derived here)
+//   torch.optim.Adam(betas=(.9,.9)).step() base_opt.py:435
+//
+// Design (HBM-bound streaming + reductions; no GEMM shape anywhere):
+//   * image-major: a workgroup owns 1024 pixels of one image and walks the (edge, side) pairs
+//     incident to that image.  The projected point of each pixel is computed once and kept in
+//     registers, the per-pixel depth gradient is complete when the walk ends, so the Adam update of
+//     the per-pixel parameter happens in the same kernel: no gradient map ever touches HBM.
+//     Traffic per iteration = 32*E*P (pred 12 B + weight 4 B, both sides) + 24*N*P (param, m, v r/w).
+//   * the 12+1 per-edge sums (sum g (x) X, sum g, loss) are reduced with DPP inside 16-lane rows, then
+//     through LDS across the workgroup, and written as per-chunk partials that a second, tiny kernel
+//     adds in a fixed order: results are bitwise reproducible (no float atomics).
+//   * the pose / focal / scale parameters (a few KB) get their chain rule + Adam in two small kernels.
+#include "common.h"
+#include <vector>
+#include <new>
+
+namespace a3r {
+
+constexpr int PXT = 4;                 // pixels per thread
+constexpr int TPB = 256;
+constexpr int CHUNK = PXT * TPB;       // pixels per workgroup
+constexpr int EB = 8;                  // (edge,side) entries per LDS reduction batch
+constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.9f, ADAM_EPS = 1e-8f;  // base_opt.py:435
+
+struct AlignDev {
+    int E, N, P, nchunks;
+    int norm_pw_scale, train_poses, train_focals, train_pp;
+    float base_scale, pw_break, focal_break;
+    float inv_area_i, inv_area_j;
+    const float *pred_i, *pred_j, *w_i, *w_j, *mono, *pp0;
+    float *pw_poses, *pw_adaptors, *depth, *shifts, *im_poses, *im_focals, *im_pp;
+    float *adam_pw_poses, *adam_depth, *adam_small;
+    // workspace
+    float *edge_xf, *img_xf, *partE, *partN, *gE, *gN, *lossE;
+    const int *inc_ptr, *inc, *slot_of, *imw, *imarea;
+    float* loss_history;
+};
+
+struct AdamArgs {
+    float lr, step_size, bc2_sqrt;
+    int step;       // 0-based index into loss_history
+};
+
+// ------------------------------------------------------------------------------------------- math helpers
+__device__ __forceinline__ void quat_to_R(const float* q, float* R, float* qn, float* nrm) {
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+    float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    float twx = tx * w, twy = ty * w, twz = tz * w;
+    float txx = tx * x, txy = ty * x, txz = tz * x;
+    float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+    if (qn) { qn[0] = x; qn[1] = y; qn[2] = z; qn[3] = w; }
+    if (nrm) *nrm = n;
+}
+
+__device__ __forceinline__ void quat_backward(const float* qn, float nrm, const double* G, double* gq) {
+    double x = qn[0], y = qn[1], z = qn[2], w = qn[3];
+    double gx = 2 * (y * G[1] + z * G[2] + y * G[3] - 2 * x * G[4] - w * G[5] + z * G[6] + w * G[7] - 2 * x * G[8]);
+    double gy = 2 * (-2 * y * G[0] + x * G[1] + w * G[2] + x * G[3] + z * G[5] - w * G[6] + z * G[7] - 2 * y * G[8]);
+    double gz = 2 * (-2 * z * G[0] - w * G[1] + x * G[2] + w * G[3] - 2 * z * G[4] + y * G[5] + x * G[6] + y * G[7]);
+    double gw = 2 * (-z * G[1] + y * G[2] + z * G[3] - x * G[5] - y * G[6] + x * G[7]);
+    double dot = gx * x + gy * y + gz * z + gw * w;
+    gq[0] = (gx - dot * x) / nrm; gq[1] = (gy - dot * y) / nrm;
+    gq[2] = (gz - dot * z) / nrm; gq[3] = (gw - dot * w) / nrm;
+}
+
+__device__ __forceinline__ float signed_expm1f(float x) {   // commons.py:118-120
+    float s = (x > 0.f) - (x < 0.f);
+    return s * expm1f(fabsf(x));
+}
+__device__ __forceinline__ float signed_expm1_grad(float x) { return x == 0.f ? 0.f : expf(fabsf(x)); }
+
+// torch.optim.Adam single-tensor update (adam.py _single_tensor_adam), in place
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    m = m + (g - m) * (1.f - ADAM_B1);
+    v = v * ADAM_B2 + (1.f - ADAM_B2) * g * g;
+    float denom = sqrtf(v) / a.bc2_sqrt + ADAM_EPS;
+    p = p - a.step_size * (m / denom);
+}
+
+// ------------------------------------------------------------------------------------------- prep
+// Per-edge [s*R*diag(a) | s*T], s, a and per-image [R | t], f, pp  (base_opt.py:177-229, optimizer.py:137-152)
+__device__ void build_transforms(const AlignDev& d, float* sh /* >= TPB floats */) {
+    const int tid = threadIdx.x;
+    float part = 0.f;
+    for (int e = tid; e < d.E; e += TPB) part += d.pw_poses[e * 8 + 7];
+    part = wave_sum(part);
+    if ((tid & 63) == 0) sh[tid >> 6] = part;
+    __syncthreads();
+    const float mean_ls = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)d.E;
+    const float nf = d.norm_pw_scale ? expf(logf(d.base_scale) - mean_ls) : 1.f;
+    for (int e = tid; e < d.E; e += TPB) {
+        const float* p = d.pw_poses + e * 8;
+        float R[9];
+        quat_to_R(p, R, nullptr, nullptr);
+        const float s = expf(p[7]) * nf;
+        float ad[3] = {d.pw_adaptors[e * 2], d.pw_adaptors[e * 2], d.pw_adaptors[e * 2 + 1]};
+        if (d.norm_pw_scale) {
+            float m = (ad[0] + ad[1] + ad[2]) / 3.f;
+            ad[0] -= m; ad[1] -= m; ad[2] -= m;
+        }
+        float a[3];
+        for (int k = 0; k < 3; k++) a[k] = expf(ad[k] / d.pw_break);
+        float* o = d.edge_xf + e * 16;
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) o[r * 4 + k] = s * R[r * 3 + k] * a[k];
+            o[r * 4 + 3] = s * signed_expm1f(p[4 + r]);
+        }
+        o[12] = s; o[13] = a[0]; o[14] = a[1]; o[15] = a[2];
+    }
+    for (int n = tid; n < d.N; n += TPB) {
+        const float* p = d.im_poses + n * 7;
+        float R[9];
+        quat_to_R(p, R, nullptr, nullptr);
+        float* o = d.img_xf + n * 16;
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) o[r * 4 + k] = R[r * 3 + k];
+            o[r * 4 + 3] = signed_expm1f(p[4 + r]);
+        }
+        o[12] = expf(d.im_focals[n] / d.focal_break);
+        o[13] = d.pp0[n * 2 + 0] + 10.f * d.im_pp[n * 2 + 0];
+        o[14] = d.pp0[n * 2 + 1] + 10.f * d.im_pp[n * 2 + 1];
+        o[15] = d.mono ? d.shifts[n] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void align_prep_kernel(AlignDev d) {
+    __shared__ float sh[TPB];
+    build_transforms(d, sh);
+}
+
+// ------------------------------------------------------------------------------------------- main
+// grid (nchunks, N).  MODE 0: loss only; 1: gradients to g_depth (no update); 2: Adam update in place.
+template <bool MONO, bool L2, int MODE>
+__global__ __launch_bounds__(TPB) void align_main_kernel(AlignDev d, AdamArgs ad, float* g_depth) {
+    __shared__ float red[2][EB][16][16];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = d.P;
+    const float* ix = d.img_xf + n * 16;
+    float R[9], T[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        R[r * 3 + 0] = ix[r * 4 + 0]; R[r * 3 + 1] = ix[r * 4 + 1]; R[r * 3 + 2] = ix[r * 4 + 2];
+        T[r] = ix[r * 4 + 3];
+    }
+    const float f = ix[12], ppx = ix[13], ppy = ix[14], shift = ix[15];
+    const float inv_f = 1.f / f;   // only used for the gradient side; forward divides like the reference
+    const int W = d.imw[n], area = d.imarea[n];
+
+    float raw[PXT], dep[PXT], ddp[PXT], gxm[PXT], gym[PXT], rel[PXT][3], proj[PXT][3], gp[PXT][3];
+    bool valid[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const int p = chunk * CHUNK + i * TPB + tid;
+        valid[i] = p < P;
+        const size_t off = (size_t)n * P + (valid[i] ? p : 0);
+        raw[i] = valid[i] ? d.depth[off] : 0.f;
+        float gx = 0.f, gy = 0.f;
+        if (p < area) { gx = (float)(p % W); gy = (float)(p / W); }
+        if (MONO) {
+            const float es = expf(raw[i]), m = valid[i] ? d.mono[off] : 0.f;
+            dep[i] = m * es + shift;
+            ddp[i] = m * es;
+        } else {
+            dep[i] = expf(raw[i]);
+            ddp[i] = dep[i];
+        }
+        gxm[i] = gx - ppx; gym[i] = gy - ppy;
+        rel[i][0] = dep[i] * gxm[i] / f;      // optimizer.py:251: depth * (pixel_grid - pp) / focal
+        rel[i][1] = dep[i] * gym[i] / f;
+        rel[i][2] = dep[i];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            proj[i][r] = R[r * 3] * rel[i][0] + R[r * 3 + 1] * rel[i][1] + R[r * 3 + 2] * rel[i][2] + T[r];
+            gp[i][r] = 0.f;
+        }
+    }
+
+    const int kbeg = d.inc_ptr[n], kend = d.inc_ptr[n + 1];
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += EB) {
+#pragma unroll 1
+        for (int kb = 0; kb < EB; kb++) {
+            const int k = k0 + kb;
+            if (k >= kend) break;
+            const int code = d.inc[k];
+            const int e = code >> 1, side = code & 1;
+            const float* M = d.edge_xf + e * 16;
+            const float m00 = M[0], m01 = M[1], m02 = M[2], m03 = M[3];
+            const float m10 = M[4], m11 = M[5], m12 = M[6], m13 = M[7];
+            const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
+            const float* X = (side ? d.pred_j : d.pred_i) + (size_t)e * P * 3;
+            const float* Wt = (side ? d.w_j : d.w_i) + (size_t)e * P;
+            const float inva = side ? d.inv_area_j : d.inv_area_i;
+            float acc[13];
+#pragma unroll
+            for (int j = 0; j < 13; j++) acc[j] = 0.f;
+            float x0[PXT], x1[PXT], x2[PXT], w[PXT];
+#pragma unroll
+            for (int i = 0; i < PXT; i++) {
+                const int p = chunk * CHUNK + i * TPB + tid;
+                const size_t pp = valid[i] ? p : 0;
+                x0[i] = X[pp * 3 + 0]; x1[i] = X[pp * 3 + 1]; x2[i] = X[pp * 3 + 2];
+                w[i] = valid[i] ? Wt[pp] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < PXT; i++) {
+                const float r0 = proj[i][0] - (m00 * x0[i] + m01 * x1[i] + m02 * x2[i] + m03);
+                const float r1 = proj[i][1] - (m10 * x0[i] + m11 * x1[i] + m12 * x2[i] + m13);
+                const float r2 = proj[i][2] - (m20 * x0[i] + m21 * x1[i] + m22 * x2[i] + m23);
+                const float sq = r0 * r0 + r1 * r1 + r2 * r2;
+                float cf;
+                if (L2) {
+                    acc[12] += sq * w[i] * inva;
+                    cf = 2.f * w[i] * inva;
+                } else {
+                    const float rho = sqrtf(sq);
+                    acc[12] += rho * w[i] * inva;
+                    cf = rho > 0.f ? w[i] / rho * inva : 0.f;
+                }
+                if (MODE != 0) {
+                    const float g0 = cf * r0, g1 = cf * r1, g2 = cf * r2;
+                    gp[i][0] += g0; gp[i][1] += g1; gp[i][2] += g2;
+                    acc[0] += g0 * x0[i]; acc[1] += g0 * x1[i]; acc[2] += g0 * x2[i];
+                    acc[3] += g1 * x0[i]; acc[4] += g1 * x1[i]; acc[5] += g1 * x2[i];
+                    acc[6] += g2 * x0[i]; acc[7] += g2 * x1[i]; acc[8] += g2 * x2[i];
+                    acc[9] += g0; acc[10] += g1; acc[11] += g2;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 13; j++) {
+                if (MODE == 0 && j < 12) continue;
+                const float s = dpp_row_sum16(acc[j]);
+                if ((lane & 15) == 0) red[buf][kb][wave * 4 + (lane >> 4)][j] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < EB * 16) {
+            const int kb = tid >> 4, j = tid & 15, k = k0 + kb;
+            if (k < kend && j < 13) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) s += red[buf][kb][r][j];
+                d.partE[((size_t)k * d.nchunks + chunk) * 16 + j] = s;
+            }
+        }
+        buf ^= 1;
+    }
+    if (MODE == 0) return;
+
+    // per-image sums and the per-pixel parameter
+    float accN[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) accN[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const float h0 = R[0] * gp[i][0] + R[3] * gp[i][1] + R[6] * gp[i][2];
+        const float h1 = R[1] * gp[i][0] + R[4] * gp[i][1] + R[7] * gp[i][2];
+        const float h2 = R[2] * gp[i][0] + R[5] * gp[i][1] + R[8] * gp[i][2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            accN[r * 3 + 0] += gp[i][r] * rel[i][0];
+            accN[r * 3 + 1] += gp[i][r] * rel[i][1];
+            accN[r * 3 + 2] += gp[i][r] * rel[i][2];
+            accN[9 + r] += gp[i][r];
+        }
+        const float gd = h0 * gxm[i] * inv_f + h1 * gym[i] * inv_f + h2;
+        accN[12] += -(h0 * rel[i][0] + h1 * rel[i][1]) / d.focal_break;
+        accN[13] += -h0 * dep[i] * inv_f * 10.f;
+        accN[14] += -h1 * dep[i] * inv_f * 10.f;
+        accN[15] += gd;
+        const float g = gd * ddp[i];
+        const int p = chunk * CHUNK + i * TPB + tid;
+        if (valid[i]) {
+            const size_t off = (size_t)n * P + p;
+            if (MODE == 1) {
+                g_depth[off] = g;
+            } else {
+                const size_t NP = (size_t)d.N * P;
+                float m = d.adam_depth[off], v = d.adam_depth[NP + off], pv = raw[i];
+                adam_update(pv, g, m, v, ad);
+                d.depth[off] = pv; d.adam_depth[off] = m; d.adam_depth[NP + off] = v;
+            }
+        }
+    }
+    __syncthreads();   // red[] may still be read by the last batch
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float s = dpp_row_sum16(accN[j]);
+        if ((lane & 15) == 0) red[0][0][wave * 4 + (lane >> 4)][j] = s;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += red[0][0][r][tid];
+        d.partN[((size_t)n * d.nchunks + chunk) * 16 + tid] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- finalize A
+// grid E + N blocks of 64 threads: fixed-order sum of the chunk partials, chain rule for the small parameters.
+__global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int loss_only) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b < d.E) {
+        const int e = b;
+        double s[13];
+        for (int j = 0; j < 13; j++) s[j] = 0.0;
+        for (int side = 0; side < 2; side++) {
+            const int k = d.slot_of[e * 2 + side];
+            const float* pe = d.partE + (size_t)k * d.nchunks * 16;
+            for (int c = lane; c < d.nchunks; c += 64)
+                for (int j = loss_only ? 12 : 0; j < 13; j++) s[j] += (double)pe[c * 16 + j];
+        }
+        for (int j = loss_only ? 12 : 0; j < 13; j++) {
+            double v = s[j];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            s[j] = v;
+        }
+        if (lane == 0) {
+            d.lossE[e] = (float)s[12];
+            if (!loss_only) {
+                const float* p = d.pw_poses + e * 8;
+                const float* xf = d.edge_xf + e * 16;
+                float R[9], qn[4], nrm;
+                quat_to_R(p, R, qn, &nrm);
+                const double sc = xf[12];
+                const float a[3] = {xf[13], xf[14], xf[15]};
+                double G[9], dLds = 0.0;
+                for (int r = 0; r < 3; r++) {
+                    for (int q = 0; q < 3; q++) {
+                        G[r * 3 + q] = -sc * a[q] * s[r * 3 + q];
+                        dLds -= (double)R[r * 3 + q] * a[q] * s[r * 3 + q];
+                    }
+                    dLds -= (double)signed_expm1f(p[4 + r]) * s[9 + r];
+                }
+                double gq[4];
+                quat_backward(qn, nrm, G, gq);
+                float* g = d.gE + e * 8;
+                for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
+                for (int k = 0; k < 3; k++) g[4 + k] = (float)(-sc * s[9 + k] * signed_expm1_grad(p[4 + k]));
+                g[7] = (float)(dLds * sc);   // S_e * s_e; the mean coupling is applied in finalize B
+            }
+        }
+    } else if (!loss_only) {
+        const int n = b - d.E;
+        double s[16];
+        for (int j = 0; j < 16; j++) s[j] = 0.0;
+        const float* pn = d.partN + (size_t)n * d.nchunks * 16;
+        for (int c = lane; c < d.nchunks; c += 64)
+            for (int j = 0; j < 16; j++) s[j] += (double)pn[c * 16 + j];
+        for (int j = 0; j < 16; j++) {
+            double v = s[j];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            s[j] = v;
+        }
+        if (lane == 0) {
+            const float* p = d.im_poses + n * 7;
+            float R[9], qn[4], nrm;
+            quat_to_R(p, R, qn, &nrm);
+            double gq[4];
+            quat_backward(qn, nrm, s, gq);
+            float* g = d.gN + n * 16;
+            for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
+            for (int k = 0; k < 3; k++) g[4 + k] = (float)(s[9 + k] * signed_expm1_grad(p[4 + k]));
+            g[7] = (float)s[12]; g[8] = (float)s[13]; g[9] = (float)s[14]; g[10] = (float)s[15];
+            for (int k = 11; k < 16; k++) g[k] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- finalize B
+// one block: scale-normalisation coupling, loss, Adam on the small parameters, transforms for the next iteration.
+// MODE 0: loss only -> loss_out; 1: gradients -> g_pw / g_small / loss_out; 2: update.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamArgs ad, float* g_pw, float* g_small,
+                                                               float* loss_out) {
+    __shared__ float sh[TPB];
+    __shared__ double shd[2][4];
+    const int tid = threadIdx.x;
+    double lsum = 0.0, ssum = 0.0;
+    for (int e = tid; e < d.E; e += TPB) {
+        lsum += (double)d.lossE[e];
+        if (MODE != 0) ssum += (double)d.gE[e * 8 + 7];
+    }
+    for (int o = 32; o > 0; o >>= 1) { lsum += __shfl_xor(lsum, o); ssum += __shfl_xor(ssum, o); }
+    if ((tid & 63) == 0) { shd[0][tid >> 6] = lsum; shd[1][tid >> 6] = ssum; }
+    __syncthreads();
+    const double loss = shd[0][0] + shd[0][1] + shd[0][2] + shd[0][3];
+    const double sumSs = shd[1][0] + shd[1][1] + shd[1][2] + shd[1][3];
+    if (tid == 0) {
+        if (MODE == 2) d.loss_history[ad.step] = (float)loss;
+        else *loss_out = (float)loss;
+    }
+    if (MODE == 0) return;
+    const float corr = d.norm_pw_scale ? (float)(sumSs / d.E) : 0.f;
+    for (int i = tid; i < d.E * 8; i += TPB) {
+        float g = d.gE[i];
+        if ((i & 7) == 7) g -= corr;
+        if (MODE == 1) {
+            g_pw[i] = g;
+        } else {
+            float m = d.adam_pw_poses[i], v = d.adam_pw_poses[d.E * 8 + i], p = d.pw_poses[i];
+            adam_update(p, g, m, v, ad);
+            d.pw_poses[i] = p; d.adam_pw_poses[i] = m; d.adam_pw_poses[d.E * 8 + i] = v;
+        }
+    }
+    for (int i = tid; i < d.N * 16; i += TPB) {
+        const int n = i >> 4, j = i & 15;
+        const float g = d.gN[i];
+        if (MODE == 1) { g_small[i] = g; continue; }
+        float* target = nullptr;
+        if (j < 7) { if (d.train_poses) target = d.im_poses + n * 7 + j; }
+        else if (j == 7) { if (d.train_focals) target = d.im_focals + n; }
+        else if (j < 10) { if (d.train_pp) target = d.im_pp + n * 2 + (j - 8); }
+        else if (j == 10) { if (d.mono) target = d.shifts + n; }
+        if (target) {
+            float m = d.adam_small[i], v = d.adam_small[d.N * 16 + i], p = *target;
+            adam_update(p, g, m, v, ad);
+            *target = p; d.adam_small[i] = m; d.adam_small[d.N * 16 + i] = v;
+        }
+    }
+    if (MODE == 2) {
+        __syncthreads();          // parameter stores above are visible to the whole workgroup
+        build_transforms(d, sh);
+    }
+}
+
+__global__ void align_export_xf_kernel(AlignDev d, float* edge_M, float* img_R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.E * 12) edge_M[i] = d.edge_xf[(i / 12) * 16 + i % 12];
+    if (i < d.N * 12) img_R[i] = d.img_xf[(i / 12) * 16 + i % 12];
+}
+
+}  // namespace a3r
+
+// =============================================================================================== host
+using namespace a3r;
+
+struct a3r_align_s {
+    AlignDev d;
+    bool use_mono, dist_l2;
+    int steps;
+    int loss_capacity;
+    bool dirty;      // parameters changed by the caller since the transforms were last built
+};
+
+static void refresh_if_dirty(a3r_align_s* a, hipStream_t st) {
+    if (a->dirty) {
+        hipLaunchKernelGGL(align_prep_kernel, dim3(1), dim3(TPB), 0, st, a->d);
+        a->dirty = false;
+    }
+}
+
+static size_t ws_layout(int E, int N, int P, size_t* off /*[12]*/) {
+    const int nch = (P + CHUNK - 1) / CHUNK;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    off[0] = take((size_t)E * 16 * 4);              // edge_xf
+    off[1] = take((size_t)N * 16 * 4);              // img_xf
+    off[2] = take((size_t)2 * E * nch * 16 * 4);    // partE
+    off[3] = take((size_t)N * nch * 16 * 4);        // partN
+    off[4] = take((size_t)E * 8 * 4);               // gE
+    off[5] = take((size_t)N * 16 * 4);              // gN
+    off[6] = take((size_t)E * 4);                   // lossE
+    off[7] = take((size_t)(N + 1) * 4);             // inc_ptr
+    off[8] = take((size_t)2 * E * 4);               // inc
+    off[9] = take((size_t)2 * E * 4);               // slot_of
+    off[10] = take((size_t)N * 4);                  // imw
+    off[11] = take((size_t)N * 4);                  // imarea
+    return o;
+}
+
+extern "C" size_t a3r_align_workspace_bytes(int E, int N, int P) {
+    size_t off[12];
+    return ws_layout(E, N, P, off);
+}
+
+extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void* stream) {
+    A3R_CHECK_ARG(s && out, "a3r_align_create: null argument");
+    A3R_CHECK_ARG(s->E > 0 && s->N > 0 && s->P > 0, "a3r_align_create: E, N, P must be positive");
+    A3R_CHECK_ARG(s->pred_i && s->pred_j && s->w_i && s->w_j && s->pp0, "a3r_align_create: missing observation buffers");
+    A3R_CHECK_ARG(s->pw_poses && s->pw_adaptors && s->depth && s->im_poses && s->im_focals && s->im_pp,
+                  "a3r_align_create: missing parameter buffers");
+    A3R_CHECK_ARG(!s->use_mono || (s->mono && s->shifts), "a3r_align_create: use_mono needs mono and shifts");
+    A3R_CHECK_ARG(s->adam_pw_poses && s->adam_depth && s->adam_small, "a3r_align_create: missing Adam state");
+    A3R_CHECK_ARG(s->loss_history && s->loss_capacity > 0, "a3r_align_create: missing loss_history");
+    size_t off[12];
+    const size_t need = ws_layout(s->E, s->N, s->P, off);
+    A3R_CHECK_ARG(s->workspace && s->workspace_bytes >= need, "a3r_align_create: workspace too small (%zu < %zu)",
+                  s->workspace_bytes, need);
+    // edge indices must be dense 0..N-1 (base_opt.py:164-167)
+    std::vector<int> deg(s->N + 1, 0), seen(s->N, 0);
+    for (int e = 0; e < s->E; e++) {
+        const int i = s->ei_host[e], j = s->ej_host[e];
+        A3R_CHECK_ARG(i >= 0 && i < s->N && j >= 0 && j < s->N, "a3r_align_create: bad pair indices (edge %d = %d,%d)", e, i, j);
+        deg[i + 1]++; deg[j + 1]++; seen[i] = seen[j] = 1;
+    }
+    for (int n = 0; n < s->N; n++) A3R_CHECK_ARG(seen[n], "bad pair indices: missing values (image %d has no edge)", n);
+    for (int n = 0; n < s->N; n++) {
+        A3R_CHECK_ARG(s->imarea_host[n] > 0 && s->imarea_host[n] <= s->P && s->imw_host[n] > 0,
+                      "a3r_align_create: bad image shape for image %d", n);
+        deg[n + 1] += deg[n];
+    }
+    std::vector<int> inc(2 * s->E), slot(2 * s->E), fill(s->N, 0);
+    for (int e = 0; e < s->E; e++) {
+        const int i = s->ei_host[e], j = s->ej_host[e];
+        int k = deg[i] + fill[i]++; inc[k] = e * 2 + 0; slot[e * 2 + 0] = k;
+        k = deg[j] + fill[j]++;     inc[k] = e * 2 + 1; slot[e * 2 + 1] = k;
+    }
+    a3r_align_s* a = new (std::nothrow) a3r_align_s();
+    A3R_CHECK_ARG(a, "out of host memory");
+    char* ws = (char*)s->workspace;
+    hipStream_t st = as_stream(stream);
+    auto up = [&](size_t o, const void* src, size_t bytes) { return hipMemcpyAsync(ws + o, src, bytes, hipMemcpyHostToDevice, st); };
+    hipError_t err = up(off[7], deg.data(), (s->N + 1) * 4);
+    if (err == hipSuccess) err = up(off[8], inc.data(), 2 * s->E * 4);
+    if (err == hipSuccess) err = up(off[9], slot.data(), 2 * s->E * 4);
+    if (err == hipSuccess) err = up(off[10], s->imw_host, s->N * 4);
+    if (err == hipSuccess) err = up(off[11], s->imarea_host, s->N * 4);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);   // host vectors go out of scope
+    if (err != hipSuccess) {
+        delete a;
+        set_error("a3r_align_create: upload failed: %s", hipGetErrorString(err));
+        return A3R_EHIP;
+    }
+    AlignDev& d = a->d;
+    d.E = s->E; d.N = s->N; d.P = s->P; d.nchunks = (s->P + CHUNK - 1) / CHUNK;
+    d.norm_pw_scale = s->norm_pw_scale; d.train_poses = s->train_poses; d.train_focals = s->train_focals;
+    d.train_pp = s->train_pp;
+    d.base_scale = s->base_scale; d.pw_break = s->pw_break; d.focal_break = s->focal_break;
+    d.inv_area_i = (float)(1.0 / s->total_area_i); d.inv_area_j = (float)(1.0 / s->total_area_j);
+    d.pred_i = s->pred_i; d.pred_j = s->pred_j; d.w_i = s->w_i; d.w_j = s->w_j;
+    d.mono = s->use_mono ? s->mono : nullptr; d.pp0 = s->pp0;
+    d.pw_poses = s->pw_poses; d.pw_adaptors = s->pw_adaptors; d.depth = s->depth; d.shifts = s->shifts;
+    d.im_poses = s->im_poses; d.im_focals = s->im_focals; d.im_pp = s->im_pp;
+    d.adam_pw_poses = s->adam_pw_poses; d.adam_depth = s->adam_depth; d.adam_small = s->adam_small;
+    d.edge_xf = (float*)(ws + off[0]); d.img_xf = (float*)(ws + off[1]);
+    d.partE = (float*)(ws + off[2]); d.partN = (float*)(ws + off[3]);
+    d.gE = (float*)(ws + off[4]); d.gN = (float*)(ws + off[5]); d.lossE = (float*)(ws + off[6]);
+    d.inc_ptr = (const int*)(ws + off[7]); d.inc = (const int*)(ws + off[8]); d.slot_of = (const int*)(ws + off[9]);
+    d.imw = (const int*)(ws + off[10]); d.imarea = (const int*)(ws + off[11]);
+    d.loss_history = s->loss_history;
+    a->use_mono = s->use_mono != 0; a->dist_l2 = s->dist_l2 != 0; a->steps = 0; a->loss_capacity = s->loss_capacity;
+    a->dirty = true;
+    *out = a;
+    return A3R_OK;
+}
+
+extern "C" int a3r_align_destroy(a3r_align_t a) {
+    delete a;
+    return A3R_OK;
+}
+
+template <int MODE>
+static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, hipStream_t st) {
+    dim3 grid(a->d.nchunks, a->d.N), block(TPB);
+    if (a->use_mono) {
+        if (a->dist_l2) hipLaunchKernelGGL((align_main_kernel<true, true, MODE>), grid, block, 0, st, a->d, ad, g_depth);
+        else hipLaunchKernelGGL((align_main_kernel<true, false, MODE>), grid, block, 0, st, a->d, ad, g_depth);
+    } else {
+        if (a->dist_l2) hipLaunchKernelGGL((align_main_kernel<false, true, MODE>), grid, block, 0, st, a->d, ad, g_depth);
+        else hipLaunchKernelGGL((align_main_kernel<false, false, MODE>), grid, block, 0, st, a->d, ad, g_depth);
+    }
+}
+
+extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {
+    A3R_CHECK_ARG(a, "a3r_align_step: null handle");
+    A3R_CHECK_ARG(a->steps < a->loss_capacity, "a3r_align_step: loss_history full (%d)", a->loss_capacity);
+    hipStream_t st = as_stream(stream);
+    const int t = a->steps + 1;
+    AdamArgs ad;
+    ad.lr = lr;
+    ad.step_size = (float)((double)lr / (1.0 - pow((double)ADAM_B1, t)));
+    ad.bc2_sqrt = (float)sqrt(1.0 - pow((double)ADAM_B2, t));
+    ad.step = a->steps;
+    refresh_if_dirty(a, st);
+    launch_main<2>(a, ad, nullptr, st);
+    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
+    hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, nullptr);
+    A3R_LAUNCH_CHECK();
+    a->steps++;
+    return A3R_OK;
+}
+
+extern "C" int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream) {
+    A3R_CHECK_ARG(a && loss_dev, "a3r_align_loss: null argument");
+    hipStream_t st = as_stream(stream);
+    AdamArgs ad = {};
+    refresh_if_dirty(a, st);
+    launch_main<0>(a, ad, nullptr, st);
+    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E), dim3(64), 0, st, a->d, 1);
+    hipLaunchKernelGGL((align_finalize_b_kernel<0>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, loss_dev);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_align_grad(a3r_align_t a, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,
+                              void* stream) {
+    A3R_CHECK_ARG(a && g_pw_poses && g_depth && g_small && loss_dev, "a3r_align_grad: null argument");
+    hipStream_t st = as_stream(stream);
+    AdamArgs ad = {};
+    refresh_if_dirty(a, st);
+    launch_main<1>(a, ad, g_depth, st);
+    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
+    hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, g_pw_poses, g_small, loss_dev);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_align_invalidate(a3r_align_t a) {
+    A3R_CHECK_ARG(a, "a3r_align_invalidate: null handle");
+    a->dirty = true;
+    return A3R_OK;
+}
+
+extern "C" int a3r_align_steps_done(a3r_align_t a) { return a ? a->steps : -1; }
+
+extern "C" int a3r_align_pose_matrices(a3r_align_t a, float* edge_M, float* img_R, void* stream) {
+    A3R_CHECK_ARG(a && edge_M && img_R, "a3r_align_pose_matrices: null argument");
+    hipStream_t st = as_stream(stream);
+    a->dirty = true;
+    refresh_if_dirty(a, st);
+    const int n = (a->d.E > a->d.N ? a->d.E : a->d.N) * 12;
+    hipLaunchKernelGGL(align_export_xf_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a->d, edge_M, img_R);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}

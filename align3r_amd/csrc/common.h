@@ -1,0 +1,71 @@
+// Shared helpers for liba3r (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/a3r.h"
+
+namespace a3r {
+
+void set_error(const char* fmt, ...);
+
+#define A3R_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            a3r::set_error(__VA_ARGS__);         \
+            return A3R_EINVAL;                   \
+        }                                        \
+    } while (0)
+
+#define A3R_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t err__ = (call);                                                             \
+        if (err__ != hipSuccess) {                                                             \
+            a3r::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+            return A3R_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define A3R_LAUNCH_CHECK()                                                                      \
+    do {                                                                                        \
+        hipError_t err__ = hipGetLastError();                                                   \
+        if (err__ != hipSuccess) {                                                              \
+            a3r::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(err__), __FILE__, __LINE__); \
+            return A3R_EHIP;                                                                    \
+        }                                                                                       \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// sum over each row of 16 lanes with DPP (every lane of the row ends with the row sum)
+__device__ __forceinline__ float dpp_row_sum16(float v) {
+#define A3R_DPP_ADD(ctrl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    A3R_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    A3R_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    A3R_DPP_ADD(0x141);  // row_half_mirror
+    A3R_DPP_ADD(0x140);  // row_mirror
+#undef A3R_DPP_ADD
+    return v;
+}
+
+// full 64-lane sum (result valid in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_row_sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+}  // namespace a3r

@@ -1,0 +1,280 @@
+// HBM-bound kernels of the pair forward: LayerNorm, standalone RoPE-2D, patchify, bilinear x2,
+// final 1x1 conv + postprocess, weight repacking.  All fp32, 16-byte vector accesses where the
+// layout allows, one wave per row for the row reductions (64-wide DPP/shuffle sums).
+#include "common.h"
+#include <cmath>
+
+namespace a3r {
+
+// ------------------------------------------------------------------------------------------- LayerNorm
+// nn.LayerNorm(D, eps) (croco.py:34; blocks.py:118-123,180-185): one wave per row, row kept in registers.
+template <int VPL>   // float4 per lane: D = 256 * VPL
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int M,
+                                                         int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        v[i] = xr[lane + 64 * i];
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        v[i] = v[i] - mean;
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w);
+    const f32x4* br = reinterpret_cast<const f32x4*>(b);
+#pragma unroll
+    for (int i = 0; i < VPL; i++) yr[lane + 64 * i] = v[i] * rstd * wr[lane + 64 * i] + br[lane + 64 * i];
+}
+
+// generic fallback (any D % 4 == 0): one wave per row, three passes over an L1/L2-resident row
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ y, int M,
+                                                                 int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) { const float c = xr[i] - mean; ss += c * c; }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
+    float* yr = y + (size_t)row * D;
+    for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * w[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------- RoPE-2D (standalone)
+// curope.rope_2d semantics (curope.cpp:11-47, kernels.cu:17-82): tokens [B,N,H,D] in place.
+__global__ void rope2d_kernel(float* tok, const int64_t* pos, int B, int N, int H, int D, float base, float fwd) {
+    const int Q = D / 4;
+    const long total = (long)B * N * H * 2 * Q;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q);
+        long r = i / Q;
+        const int xy = (int)(r % 2); r /= 2;
+        const int hh = (int)(r % H); r /= H;      // r = b*N + n
+        const float p = (float)pos[r * 2 + xy];
+        const float ang = fwd * p / powf(base, (float)q / (float)Q);
+        const float c = cosf(ang), s = sinf(ang);
+        float* t = tok + (r * H + hh) * (long)D + xy * 2 * Q + q;
+        const float u = t[0], v = t[Q];
+        t[0] = u * c - v * s;
+        t[Q] = v * c + u * s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- patchify
+// cols[(b*nh + ty)*nw + tx][c*256 + py*16 + px] = img(b, c, ty*16+py, tx*16+px)
+__global__ void patchify_kernel(const float* __restrict__ img, float* __restrict__ cols, int B, int C, int H, int W,
+                                long sb, long sc, long sy, long sx) {
+    const int nh = H / 16, nw = W / 16, K = C * 256;
+    const long total = (long)B * nh * nw * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long t = i / K;
+        const int tx = (int)(t % nw), ty = (int)((t / nw) % nh), b = (int)(t / ((long)nw * nh));
+        const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+        cols[i] = img[b * sb + c * sc + (long)(ty * 16 + py) * sy + (long)(tx * 16 + px) * sx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- bilinear x2, align_corners=True
+// Index arithmetic in fp32 exactly as ATen's upsample_bilinear2d (scale = (in-1)/(out-1); src = scale*dst).
+__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
+                                  int Hc, int Wc) {
+    const float sh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+    const float sw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    const long total = (long)B * Hc * Wc * C4;
+    const f32x4* xv = reinterpret_cast<const f32x4*>(x);
+    f32x4* yv = reinterpret_cast<f32x4*>(y);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long t = i / C4;
+        const int ox = (int)(t % Wc); t /= Wc;
+        const int oy = (int)(t % Hc);
+        const int b = (int)(t / Hc);
+        const float fy = sh * (float)oy, fx = sw * (float)ox;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = y0 < H - 1 ? y0 : H - 1; x0 = x0 < W - 1 ? x0 : W - 1;
+        const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const long rb = (long)b * H;
+        const f32x4 v00 = xv[((rb + y0) * W + x0) * C4 + c], v01 = xv[((rb + y0) * W + x1) * C4 + c];
+        const f32x4 v10 = xv[((rb + y1) * W + x0) * C4 + c], v11 = xv[((rb + y1) * W + x1) * C4 + c];
+        yv[i] = (v00 * lx0 + v01 * lx1) * ly0 + (v10 * lx0 + v11 * lx1) * ly1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- head final
+// conv1x1 C -> 4 (+bias) then postprocess (postprocess.py:10-58). 32 lanes per pixel (C == 128: one float4 each).
+__global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ pts,
+                                                          float* __restrict__ conf, long P, int C) {
+    const int lane = threadIdx.x & 63, sub = lane & 31;
+    const long pix0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const long stride = (long)gridDim.x * 8;
+    const long iters = (P + stride - 1) / stride;      // uniform trip count: the shuffles need every lane
+    const int nvec = C / 4;
+    for (long it = 0; it < iters; it++) {
+        const long pix = pix0 + it * stride;
+        const bool ok = pix < P;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(x + pix * C);
+            for (int j = sub; j < nvec; j += 32) {
+                const f32x4 v = xr[j];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const f32x4 ww = reinterpret_cast<const f32x4*>(w + o * C)[j];
+                    acc[o] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+#pragma unroll
+            for (int m = 16; m > 0; m >>= 1) acc[o] += __shfl_xor(acc[o], m);
+            acc[o] += bias[o];
+        }
+        if (ok && sub == 0) {
+            // reference order: xyz / d.clip(1e-8) * expm1(d)   (postprocess.py:37-46)
+            const float d = sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+            const float dd = fmaxf(d, 1e-8f), em = expm1f(d);
+            pts[pix * 3 + 0] = acc[0] / dd * em;
+            pts[pix * 3 + 1] = acc[1] / dd * em;
+            pts[pix * 3 + 2] = acc[2] / dd * em;
+            conf[pix] = 1.f + expf(acc[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- weight repacking
+// [Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin]
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+    const long total = (long)Cout * Cin * 9;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const int tap = (int)((i / Cin) % 9);
+        const int co = (int)(i / ((long)Cin * 9));
+        wp[i] = w[((long)co * Cin + ci) * 9 + tap];
+    }
+}
+// [Cin, Cout, s, s] -> [(dy*s+dx)*Cout + co][Cin]
+__global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int s) {
+    const long total = (long)Cin * Cout * s * s;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const long n = i / Cin;
+        const int co = (int)(n % Cout), tap = (int)(n / Cout);
+        wp[i] = w[((long)ci * Cout + co) * (s * s) + tap];
+    }
+}
+
+static inline int grid_for(long total, int block = 256) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+}  // namespace a3r
+using namespace a3r;
+
+extern "C" int a3r_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps,
+                             void* stream) {
+    A3R_CHECK_ARG(x && w && b && y, "a3r_layernorm: null pointer");
+    A3R_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0, "a3r_layernorm: bad shape M=%d D=%d", M, D);
+    hipStream_t st = as_stream(stream);
+    dim3 grid((M + 3) / 4), block(256);
+    if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (D == 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (D == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_rope2d(float* tokens, const int64_t* positions, int B, int N, int H, int D, float base, float fwd,
+                          void* stream) {
+    // argument checks mirror curope.cpp:54-59 / kernels.cu:91-94
+    A3R_CHECK_ARG(tokens && positions, "a3r_rope2d: null pointer");
+    A3R_CHECK_ARG(B > 0 && N > 0 && H > 0, "a3r_rope2d: tokens must have 4 dimensions with positive sizes");
+    A3R_CHECK_ARG(D > 0 && D % 4 == 0, "a3r_rope2d: token dim must be multiple of 4 (got %d)", D);
+    const long total = (long)B * N * H * (D / 2);
+    hipLaunchKernelGGL(rope2d_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), tokens, positions, B, N, H, D,
+                       base, fwd);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_rope_table_host(float* cos_host, float* sin_host, int max_pos, float base) {
+    A3R_CHECK_ARG(cos_host && sin_host && max_pos > 0, "a3r_rope_table_host: bad argument");
+    // RoPE2D.get_cos_sin (pos_embed.py:118-128) with D = 32: inv_freq = 1/(base**(arange(0,32,2)/32)), fp32 steps
+    for (int q = 0; q < 16; q++) {
+        const float expo = (float)(2 * q) / 32.0f;
+        const float inv_freq = 1.0f / powf(base, expo);
+        for (int p = 0; p < max_pos; p++) {
+            const float fr = (float)p * inv_freq;
+            cos_host[p * 16 + q] = cosf(fr);
+            sin_host[p * 16 + q] = sinf(fr);
+        }
+    }
+    return A3R_OK;
+}
+
+extern "C" int a3r_patchify(const float* img, float* cols, int B, int C, int H, int W, long sb, long sc, long sy, long sx,
+                            void* stream) {
+    A3R_CHECK_ARG(img && cols, "a3r_patchify: null pointer");
+    // patch_embed.py:22-23
+    A3R_CHECK_ARG(H > 0 && H % 16 == 0, "Input image height (%d) is not a multiple of patch size (16).", H);
+    A3R_CHECK_ARG(W > 0 && W % 16 == 0, "Input image width (%d) is not a multiple of patch size (16).", W);
+    const long total = (long)B * (H / 16) * (W / 16) * C * 256;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), img, cols, B, C, H, W, sb, sc,
+                       sy, sx);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream) {
+    A3R_CHECK_ARG(x && y, "a3r_upsample2x: null pointer");
+    A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "a3r_upsample2x: bad shape");
+    A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x: crop window larger than the 2x map");
+    const long total = (long)B * Hc * Wc * (C / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_head_final(const float* x, const float* w, const float* b, float* pts3d, float* conf, long P, int C,
+                              void* stream) {
+    A3R_CHECK_ARG(x && w && b && pts3d && conf, "a3r_head_final: null pointer");
+    A3R_CHECK_ARG(P > 0 && C > 0 && C % 4 == 0, "a3r_head_final: bad shape");
+    long blocks = (P + 7) / 8;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(head_final_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, w, b, pts3d, conf, P, C);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_pack_conv3x3(const float* w, float* wp, int Cout, int Cin, void* stream) {
+    A3R_CHECK_ARG(w && wp && Cout > 0 && Cin > 0, "a3r_pack_conv3x3: bad argument");
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((long)Cout * Cin * 9)), dim3(256), 0, as_stream(stream), w, wp, Cout, Cin);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_pack_convT(const float* w, float* wp, int Cin, int Cout, int s, void* stream) {
+    A3R_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && s > 0, "a3r_pack_convT: bad argument");
+    hipLaunchKernelGGL(pack_convT_kernel, dim3(grid_for((long)Cin * Cout * s * s)), dim3(256), 0, as_stream(stream), w, wp, Cin, Cout, s);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}

@@ -1,0 +1,613 @@
+// AsymmetricCroCo3DStereo.forward as a fixed launch plan over liba3r's kernels (host code only).
+//
+// Mirrors, step for step (all under /root/reference/):
+//   forward / _encode_image_pairs / _encode_image   dust3r/model.py:241-257,151-174
+//   _decoder (+ dec_blocks_pc / zero_convs branch)  dust3r/model.py:201-233
+//   Block / DecoderBlock                             croco/models/blocks.py:114-191
+//   DPTOutputAdapter_fix.forward                     dust3r/heads/dpt_head.py:34-66
+//   postprocess                                      dust3r/heads/postprocess.py:10-58
+// Data layout: tokens [rows, C] with rows = (side, batch, token): the first B*N rows belong to view 1,
+// the next B*N rows to view 2 (this is the reference's torch.cat((img1, img2)) batch order), maps are
+// channels-last.  All buffers live in the caller's workspace; nothing here allocates device memory.
+#include "common.h"
+#include <map>
+#include <string>
+#include <vector>
+#include <new>
+#include <cstdlib>
+
+namespace a3r {
+
+struct WRef { const float* p = nullptr; std::vector<int64_t> shape; };
+
+struct Arena {
+    char* base; size_t off, cap; bool dry; size_t peak; bool overflow = false;
+    float* alloc(size_t nfloat) {
+        size_t o = off;
+        off = align_up(off + nfloat * 4, 256);
+        if (off > peak) peak = off;
+        if (!dry && off > cap) { overflow = true; return reinterpret_cast<float*>(base); }
+        return dry ? nullptr : reinterpret_cast<float*>(base + o);
+    }
+};
+
+struct BlockW {
+    const float *n1w, *n1b, *qkvw, *qkvb, *projw, *projb, *n2w, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
+    // decoder only
+    const float *qw, *qb, *kvw, *kvb, *cprojw, *cprojb, *n3w, *n3b, *nyw, *nyb;
+};
+
+struct RcuW { const float *c1w, *c1b, *c2w, *c2b; };
+struct FusionW { RcuW r1, r2; const float *ow, *ob; };
+struct HeadW {
+    const float *a0w, *a0b, *a0tw, *a0tb, *a1w, *a1b, *a1tw, *a1tb, *a2w, *a2b, *a3w, *a3b, *a3cw, *a3cb;
+    const float* rn[4];
+    FusionW ref[4];   // ref[0] = refinenet1 ... ref[3] = refinenet4
+    const float *h0w, *h0b, *h2w, *h2b, *h4w, *h4b;
+};
+
+}  // namespace a3r
+using namespace a3r;
+
+struct a3r_model_s {
+    a3r_model_config cfg;
+    std::map<std::string, WRef> w;
+    bool finalized = false;
+    std::vector<BlockW> enc, pc, dec1, dec2;
+    HeadW head[2];
+    const float *pe_w, *pe_b, *pepc_w, *pepc_b, *encn_w, *encn_b, *de_w, *de_b, *decn_w, *decn_b;
+    std::vector<const float*> zc_w, zc_b;
+    const float *rope_cos = nullptr, *rope_sin = nullptr;
+    std::vector<float> host_cos, host_sin;
+    std::map<std::string, std::pair<const float*, size_t>> taps;
+    static constexpr int MAX_POS = 256;
+};
+
+static int n_pc_blocks(const a3r_model_config& c) { return c.dec_depth / 2 - 2; }
+
+extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
+    A3R_CHECK_ARG(cfg && out, "a3r_model_create: null argument");
+    A3R_CHECK_ARG(cfg->enc_embed_dim == cfg->enc_num_heads * 64 && cfg->dec_embed_dim == cfg->dec_num_heads * 64,
+                  "a3r_model_create: head_dim must be 64 (enc %d/%d, dec %d/%d)", cfg->enc_embed_dim, cfg->enc_num_heads,
+                  cfg->dec_embed_dim, cfg->dec_num_heads);
+    A3R_CHECK_ARG(cfg->patch_size == 16, "a3r_model_create: patch_size must be 16");
+    A3R_CHECK_ARG(cfg->dec_depth > 9, "a3r_model_create: dec_depth must be > 9 (dpt_head.py:101)");
+    A3R_CHECK_ARG(cfg->enc_embed_dim % 32 == 0 && cfg->dec_embed_dim % 32 == 0 && cfg->feature_dim % 32 == 0 &&
+                      cfg->last_dim % 32 == 0, "a3r_model_create: widths must be multiples of 32");
+    for (int i = 0; i < 4; i++) A3R_CHECK_ARG(cfg->layer_dims[i] % 32 == 0, "a3r_model_create: layer_dims must be multiples of 32");
+    a3r_model_s* m = new (std::nothrow) a3r_model_s();
+    A3R_CHECK_ARG(m, "out of host memory");
+    m->cfg = *cfg;
+    *out = m;
+    return A3R_OK;
+}
+
+extern "C" int a3r_model_destroy(a3r_model_t m) {
+    delete m;
+    return A3R_OK;
+}
+
+extern "C" int a3r_model_set_weight(a3r_model_t m, const char* name, const float* ptr, int ndim, const int64_t* shape) {
+    A3R_CHECK_ARG(m && name && ptr && ndim >= 1 && ndim <= 4 && shape, "a3r_model_set_weight: bad argument");
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "a3r_model_set_weight: %s is not 16-byte aligned", name);
+    WRef r;
+    r.p = ptr;
+    r.shape.assign(shape, shape + ndim);
+    m->w[name] = r;
+    m->finalized = false;
+    return A3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------- packing plan
+namespace {
+struct PackItem { std::string name; int kind; int a, b, s; size_t off; };   // kind 0: conv3x3 [Cout=a,Cin=b]; 1: convT [Cin=a,Cout=b,s]; 2: kv-concat (D=a)
+
+std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
+    const a3r_model_config& c = m->cfg;
+    std::vector<PackItem> v;
+    size_t off = 0;
+    auto add = [&](const std::string& n, int kind, int a, int b, int s, size_t nfloat) {
+        v.push_back({n, kind, a, b, s, off});
+        off = align_up(off + nfloat * 4, 256);
+    };
+    const int F = c.feature_dim;
+    for (int h = 1; h <= 2; h++) {
+        const std::string p = "downstream_head" + std::to_string(h) + ".dpt.";
+        for (int i = 0; i < 4; i++) add(p + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 0, F, c.layer_dims[i], 0, (size_t)F * c.layer_dims[i] * 9);
+        for (int r = 1; r <= 4; r++)
+            for (int u = 1; u <= 2; u++)
+                for (int k = 1; k <= 2; k++)
+                    add(p + "scratch.refinenet" + std::to_string(r) + ".resConfUnit" + std::to_string(u) + ".conv" + std::to_string(k) + ".weight", 0, F, F, 0, (size_t)F * F * 9);
+        add(p + "head.0.weight", 0, F / 2, F, 0, (size_t)(F / 2) * F * 9);
+        add(p + "head.2.weight", 0, c.last_dim, F / 2, 0, (size_t)c.last_dim * (F / 2) * 9);
+        add(p + "act_postprocess.3.1.weight", 0, c.layer_dims[3], c.layer_dims[3], 0, (size_t)c.layer_dims[3] * c.layer_dims[3] * 9);
+        add(p + "act_postprocess.0.1.weight", 1, c.layer_dims[0], c.layer_dims[0], 4, (size_t)c.layer_dims[0] * c.layer_dims[0] * 16);
+        add(p + "act_postprocess.1.1.weight", 1, c.layer_dims[1], c.layer_dims[1], 2, (size_t)c.layer_dims[1] * c.layer_dims[1] * 4);
+    }
+    const int D = c.dec_embed_dim;
+    for (int d = 0; d < 2; d++)
+        for (int i = 0; i < c.dec_depth; i++) {
+            const std::string p = std::string(d ? "dec_blocks2." : "dec_blocks.") + std::to_string(i) + ".cross_attn.";
+            add(p + "kv", 2, D, 0, 0, (size_t)2 * D * D + 2 * D);
+        }
+    v.push_back({"rope", 3, 0, 0, 0, off});
+    off = align_up(off + (size_t)2 * a3r_model_s::MAX_POS * 16 * 4, 256);
+    *total = off;
+    return v;
+}
+}  // namespace
+
+extern "C" size_t a3r_model_packed_bytes(a3r_model_t m) {
+    if (!m) return 0;
+    size_t total = 0;
+    pack_plan(m, &total);
+    return total;
+}
+
+static int need(a3r_model_s* m, const std::string& name, std::vector<int64_t> shape, const float** out) {
+    auto it = m->w.find(name);
+    if (it == m->w.end()) {
+        set_error("a3r_model_finalize: missing weight '%s'", name.c_str());
+        return A3R_ESTATE;
+    }
+    if (it->second.shape != shape) {
+        std::string got, want;
+        for (auto d : it->second.shape) got += std::to_string(d) + ",";
+        for (auto d : shape) want += std::to_string(d) + ",";
+        set_error("a3r_model_finalize: weight '%s' has shape [%s] but [%s] is required", name.c_str(), got.c_str(), want.c_str());
+        return A3R_EINVAL;
+    }
+    *out = it->second.p;
+    return A3R_OK;
+}
+
+#define NEED(name, out, ...)                                         \
+    do {                                                             \
+        if (int rc__ = need(m, name, {__VA_ARGS__}, out)) return rc__; \
+    } while (0)
+
+static int bind_block(a3r_model_s* m, const std::string& p, int D, int hidden, bool cross, BlockW* b) {
+    NEED(p + ".norm1.weight", &b->n1w, D); NEED(p + ".norm1.bias", &b->n1b, D);
+    NEED(p + ".attn.qkv.weight", &b->qkvw, 3 * D, D); NEED(p + ".attn.qkv.bias", &b->qkvb, 3 * D);
+    NEED(p + ".attn.proj.weight", &b->projw, D, D); NEED(p + ".attn.proj.bias", &b->projb, D);
+    NEED(p + ".norm2.weight", &b->n2w, D); NEED(p + ".norm2.bias", &b->n2b, D);
+    NEED(p + ".mlp.fc1.weight", &b->fc1w, hidden, D); NEED(p + ".mlp.fc1.bias", &b->fc1b, hidden);
+    NEED(p + ".mlp.fc2.weight", &b->fc2w, D, hidden); NEED(p + ".mlp.fc2.bias", &b->fc2b, D);
+    if (cross) {
+        const float* t;
+        NEED(p + ".cross_attn.projq.weight", &b->qw, D, D); NEED(p + ".cross_attn.projq.bias", &b->qb, D);
+        NEED(p + ".cross_attn.projk.weight", &t, D, D); NEED(p + ".cross_attn.projk.bias", &t, D);
+        NEED(p + ".cross_attn.projv.weight", &t, D, D); NEED(p + ".cross_attn.projv.bias", &t, D);
+        NEED(p + ".cross_attn.proj.weight", &b->cprojw, D, D); NEED(p + ".cross_attn.proj.bias", &b->cprojb, D);
+        NEED(p + ".norm3.weight", &b->n3w, D); NEED(p + ".norm3.bias", &b->n3b, D);
+        NEED(p + ".norm_y.weight", &b->nyw, D); NEED(p + ".norm_y.bias", &b->nyb, D);
+    }
+    return A3R_OK;
+}
+
+extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_bytes, void* stream) {
+    A3R_CHECK_ARG(m && packed, "a3r_model_finalize: null argument");
+    size_t total = 0;
+    std::vector<PackItem> plan = pack_plan(m, &total);
+    A3R_CHECK_ARG(packed_bytes >= total, "a3r_model_finalize: packed buffer too small (%zu < %zu)", packed_bytes, total);
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 255) == 0, "a3r_model_finalize: packed buffer must be 256-byte aligned");
+    const a3r_model_config& c = m->cfg;
+    const int E = c.enc_embed_dim, D = c.dec_embed_dim, F = c.feature_dim, L = c.last_dim;
+    hipStream_t st = as_stream(stream);
+    char* pk = static_cast<char*>(packed);
+    std::map<std::string, const float*> packed_ptr;
+    // --- repack
+    for (const PackItem& it : plan) {
+        float* dst = reinterpret_cast<float*>(pk + it.off);
+        if (it.kind == 0) {
+            const float* src;
+            NEED(it.name, &src, it.a, it.b, 3, 3);
+            if (int rc = a3r_pack_conv3x3(src, dst, it.a, it.b, stream)) return rc;
+        } else if (it.kind == 1) {
+            const float* src;
+            NEED(it.name, &src, it.a, it.b, it.s, it.s);
+            if (int rc = a3r_pack_convT(src, dst, it.a, it.b, it.s, stream)) return rc;
+        } else if (it.kind == 2) {
+            const std::string p = it.name.substr(0, it.name.size() - 2);   // strip "kv"
+            const float *kw, *kb, *vw, *vb;
+            NEED(p + "projk.weight", &kw, D, D); NEED(p + "projk.bias", &kb, D);
+            NEED(p + "projv.weight", &vw, D, D); NEED(p + "projv.bias", &vb, D);
+            const size_t DD = (size_t)D * D * 4;
+            A3R_HIP(hipMemcpyAsync(dst, kw, DD, hipMemcpyDeviceToDevice, st));
+            A3R_HIP(hipMemcpyAsync(dst + (size_t)D * D, vw, DD, hipMemcpyDeviceToDevice, st));
+            A3R_HIP(hipMemcpyAsync(dst + (size_t)2 * D * D, kb, D * 4, hipMemcpyDeviceToDevice, st));
+            A3R_HIP(hipMemcpyAsync(dst + (size_t)2 * D * D + D, vb, D * 4, hipMemcpyDeviceToDevice, st));
+        } else {
+            m->host_cos.resize(a3r_model_s::MAX_POS * 16);
+            m->host_sin.resize(a3r_model_s::MAX_POS * 16);
+            a3r_rope_table_host(m->host_cos.data(), m->host_sin.data(), a3r_model_s::MAX_POS, c.rope_base);
+            A3R_HIP(hipMemcpyAsync(dst, m->host_cos.data(), m->host_cos.size() * 4, hipMemcpyHostToDevice, st));
+            A3R_HIP(hipMemcpyAsync(dst + a3r_model_s::MAX_POS * 16, m->host_sin.data(), m->host_sin.size() * 4, hipMemcpyHostToDevice, st));
+            m->rope_cos = dst;
+            m->rope_sin = dst + a3r_model_s::MAX_POS * 16;
+        }
+        packed_ptr[it.name] = dst;
+    }
+    // --- bind
+    NEED("patch_embed.proj.weight", &m->pe_w, E, 3, 16, 16); NEED("patch_embed.proj.bias", &m->pe_b, E);
+    NEED("patch_embed_point_cloud.proj.weight", &m->pepc_w, D, 3, 16, 16); NEED("patch_embed_point_cloud.proj.bias", &m->pepc_b, D);
+    NEED("enc_norm.weight", &m->encn_w, E); NEED("enc_norm.bias", &m->encn_b, E);
+    NEED("decoder_embed.weight", &m->de_w, D, E); NEED("decoder_embed.bias", &m->de_b, D);
+    NEED("dec_norm.weight", &m->decn_w, D); NEED("dec_norm.bias", &m->decn_b, D);
+    m->enc.assign(c.enc_depth, BlockW());
+    for (int i = 0; i < c.enc_depth; i++)
+        if (int rc = bind_block(m, "enc_blocks." + std::to_string(i), E, E * c.mlp_ratio, false, &m->enc[i])) return rc;
+    const int npc = n_pc_blocks(c);
+    m->pc.assign(npc, BlockW());
+    for (int i = 0; i < npc; i++)
+        if (int rc = bind_block(m, "dec_blocks_pc." + std::to_string(i), D, D * c.mlp_ratio, false, &m->pc[i])) return rc;
+    m->dec1.assign(c.dec_depth, BlockW());
+    m->dec2.assign(c.dec_depth, BlockW());
+    for (int i = 0; i < c.dec_depth; i++) {
+        if (int rc = bind_block(m, "dec_blocks." + std::to_string(i), D, D * c.mlp_ratio, true, &m->dec1[i])) return rc;
+        if (int rc = bind_block(m, "dec_blocks2." + std::to_string(i), D, D * c.mlp_ratio, true, &m->dec2[i])) return rc;
+        const float* kv1 = packed_ptr["dec_blocks." + std::to_string(i) + ".cross_attn.kv"];
+        const float* kv2 = packed_ptr["dec_blocks2." + std::to_string(i) + ".cross_attn.kv"];
+        m->dec1[i].kvw = kv1; m->dec1[i].kvb = kv1 + (size_t)2 * D * D;
+        m->dec2[i].kvw = kv2; m->dec2[i].kvb = kv2 + (size_t)2 * D * D;
+    }
+    m->zc_w.assign(npc + 1, nullptr);
+    m->zc_b.assign(npc + 1, nullptr);
+    for (int i = 0; i <= npc; i++) {
+        NEED("zero_convs." + std::to_string(i) + ".0.weight", &m->zc_w[i], D, D, 1);
+        NEED("zero_convs." + std::to_string(i) + ".0.bias", &m->zc_b[i], D);
+    }
+    for (int h = 0; h < 2; h++) {
+        HeadW& H = m->head[h];
+        const std::string p = "downstream_head" + std::to_string(h + 1) + ".dpt.";
+        const int* ld = c.layer_dims;
+        NEED(p + "act_postprocess.0.0.weight", &H.a0w, ld[0], E, 1, 1); NEED(p + "act_postprocess.0.0.bias", &H.a0b, ld[0]);
+        NEED(p + "act_postprocess.0.1.bias", &H.a0tb, ld[0]);
+        NEED(p + "act_postprocess.1.0.weight", &H.a1w, ld[1], D, 1, 1); NEED(p + "act_postprocess.1.0.bias", &H.a1b, ld[1]);
+        NEED(p + "act_postprocess.1.1.bias", &H.a1tb, ld[1]);
+        NEED(p + "act_postprocess.2.0.weight", &H.a2w, ld[2], D, 1, 1); NEED(p + "act_postprocess.2.0.bias", &H.a2b, ld[2]);
+        NEED(p + "act_postprocess.3.0.weight", &H.a3w, ld[3], D, 1, 1); NEED(p + "act_postprocess.3.0.bias", &H.a3b, ld[3]);
+        NEED(p + "act_postprocess.3.1.bias", &H.a3cb, ld[3]);
+        H.a0tw = packed_ptr[p + "act_postprocess.0.1.weight"];
+        H.a1tw = packed_ptr[p + "act_postprocess.1.1.weight"];
+        H.a3cw = packed_ptr[p + "act_postprocess.3.1.weight"];
+        for (int i = 0; i < 4; i++) H.rn[i] = packed_ptr[p + "scratch.layer" + std::to_string(i + 1) + "_rn.weight"];
+        for (int r = 0; r < 4; r++) {
+            const std::string q = p + "scratch.refinenet" + std::to_string(r + 1) + ".";
+            NEED(q + "out_conv.weight", &H.ref[r].ow, F, F, 1, 1); NEED(q + "out_conv.bias", &H.ref[r].ob, F);
+            RcuW* rr[2] = {&H.ref[r].r1, &H.ref[r].r2};
+            for (int u = 0; u < 2; u++) {
+                const std::string qq = q + "resConfUnit" + std::to_string(u + 1) + ".";
+                rr[u]->c1w = packed_ptr[qq + "conv1.weight"]; rr[u]->c2w = packed_ptr[qq + "conv2.weight"];
+                NEED(qq + "conv1.bias", &rr[u]->c1b, F); NEED(qq + "conv2.bias", &rr[u]->c2b, F);
+            }
+        }
+        H.h0w = packed_ptr[p + "head.0.weight"]; NEED(p + "head.0.bias", &H.h0b, F / 2);
+        H.h2w = packed_ptr[p + "head.2.weight"]; NEED(p + "head.2.bias", &H.h2b, L);
+        NEED(p + "head.4.weight", &H.h4w, 4, L, 1, 1); NEED(p + "head.4.bias", &H.h4b, 4);
+    }
+    m->finalized = true;
+    return A3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------- launch plan
+namespace {
+
+struct Plan {
+    a3r_model_s* m;
+    Arena ar;
+    void* stream;
+    int rc = A3R_OK;
+    bool trace = getenv("A3R_TRACE") != nullptr;   // debugging aid: name + synchronise every op
+    int opno = 0;
+    bool dry() const { return ar.dry; }
+    bool skip() {
+        if (ar.overflow && !rc) {
+            set_error("a3r_model_forward: internal workspace plan overflow (sizing pass and launch pass disagree)");
+            rc = A3R_ESTATE;
+        }
+        return dry() || rc != A3R_OK;
+    }
+    void traced(const char* what, int a = 0, int b = 0, int c = 0) {
+        if (!trace || dry()) return;
+        hipError_t e = hipStreamSynchronize(as_stream(stream));
+        fprintf(stderr, "[a3r trace] op %d before %s(%d,%d,%d): previous ops %s\n", opno++, what, a, b, c,
+                e == hipSuccess ? "ok" : hipGetErrorString(e));
+        fflush(stderr);
+    }
+
+    a3r_epilogue epi(int kind, const float* bias, const float* resid = nullptr, const float* resid2 = nullptr) {
+        a3r_epilogue e = {};
+        e.epi = kind; e.bias = bias; e.resid = resid; e.resid2 = resid2;
+        return e;
+    }
+    void linear(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e) {
+        if (skip()) return;
+        traced("linear", M, N, K);
+        rc = a3r_linear(x, lda, w, y, ldc, M, N, K, &e, stream);
+    }
+    void ln(const float* x, const float* w, const float* b, float* y, int M, int D) {
+        if (skip()) return;
+        traced("layernorm", M, D);
+        rc = a3r_layernorm(x, w, b, y, M, D, 1e-6f, stream);
+    }
+    void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
+        if (skip()) return;
+        traced("attention", B, Nq, Nk);
+        rc = a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
+    }
+    void conv(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
+        if (skip()) return;
+        traced("conv3x3", H, W, Cin);
+        rc = a3r_conv3x3(x, wp, y, B, H, W, Cin, Cout, stride, &e, stream);
+    }
+    void up(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc) {
+        if (skip()) return;
+        traced("upsample2x", H, W, C);
+        rc = a3r_upsample2x(x, y, B, H, W, C, Hc, Wc, stream);
+    }
+    a3r_epilogue rope_epi(const float* bias, int rope_cols, int ntok, int gw) {
+        a3r_epilogue e = epi(A3R_EPI_ROPE, bias);
+        e.rope_cols = rope_cols; e.tokens_per_image = ntok; e.grid_w = gw;
+        e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
+        return e;
+    }
+
+    // Block.forward blocks.py:127-130 on x [M, D] in place (self-attention over images of ntok tokens)
+    void self_block(const BlockW& w, float* x, const float* resid_src, int M, int D, int H, int ntok, int gw, int hidden,
+                    float* xn, float* qkv, float* att, float* hid) {
+        // x_out = resid_src + attn(LN1(resid_src)); then MLP in place on x
+        ln(resid_src, w.n1w, w.n1b, xn, M, D);
+        linear(xn, D, w.qkvw, qkv, 3 * D, M, 3 * D, D, rope_epi(w.qkvb, 2 * D, ntok, gw));
+        attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, M / ntok, H, ntok, ntok);
+        linear(att, D, w.projw, x, D, M, D, D, epi(A3R_EPI_RESID, w.projb, resid_src));
+        (void)hidden; (void)hid;
+    }
+    void mlp(const BlockW& w, const float* nw, const float* nb, float* x, int M, int D, int hidden, float* xn, float* hid) {
+        ln(x, nw, nb, xn, M, D);
+        linear(xn, D, w.fc1w, hid, hidden, M, hidden, D, epi(A3R_EPI_GELU, w.fc1b));
+        linear(hid, hidden, w.fc2w, x, D, M, D, hidden, epi(A3R_EPI_RESID, w.fc2b, x));
+    }
+};
+
+// rcu (dpt_block.py:120-142): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
+void rcu(Plan& P, const RcuW& w, const float* x, const float* extra, float* tmp, float* out, int B, int H, int W, int F) {
+    a3r_epilogue e1 = P.epi(A3R_EPI_RELU, w.c1b);
+    e1.relu_a = 1;
+    P.conv(x, w.c1w, tmp, B, H, W, F, F, 1, e1);
+    a3r_epilogue e2 = extra ? P.epi(A3R_EPI_RESID2, w.c2b, x, extra) : P.epi(A3R_EPI_RESID, w.c2b, x);
+    P.conv(tmp, w.c2w, out, B, H, W, F, F, 1, e2);
+}
+
+// FeatureFusionBlock_custom.forward (dpt_block.py:186-218): returns [B, Hc, Wc, F] with (Hc,Wc) = crop of (2H,2W)
+// (`two` says whether xs[1] exists: pointers are null during the dry sizing pass, so it cannot be inferred from x1)
+float* fusion(Plan& P, const FusionW& w, const float* x0, const float* x1, bool two, int B, int H, int W, int F, int Hc, int Wc) {
+    Arena& ar = P.ar;
+    const size_t n = (size_t)B * H * W * F;
+    float* tmp = ar.alloc(n);
+    float* cur;
+    if (two) {
+        float* s = ar.alloc(n);
+        rcu(P, w.r1, x1, x0, tmp, s, B, H, W, F);     // output + resConfUnit1(xs[1])
+        cur = s;
+    } else {
+        cur = const_cast<float*>(x0);
+    }
+    float* o = ar.alloc(n);
+    rcu(P, w.r2, cur, nullptr, tmp, o, B, H, W, F);
+    float* u = ar.alloc((size_t)B * Hc * Wc * F);
+    P.up(o, u, B, H, W, F, Hc, Wc);
+    float* r = ar.alloc((size_t)B * Hc * Wc * F);
+    P.linear(u, F, w.ow, r, F, B * Hc * Wc, F, F, P.epi(A3R_EPI_NONE, w.ob));
+    return r;
+}
+
+int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, const float* pd1, const float* pd2, int B,
+             int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, void* ws, size_t ws_bytes, void* stream,
+             size_t* peak) {
+    const a3r_model_config& c = m->cfg;
+    const int E = c.enc_embed_dim, D = c.dec_embed_dim, F = c.feature_dim, L = c.last_dim;
+    const int nh = H / 16, nw = W / 16, N = nh * nw, BN = B * N, M2 = 2 * BN;
+    Plan P;
+    P.m = m; P.stream = stream;
+    P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};
+    Arena& ar = P.ar;
+    // ---------------- persistent buffers
+    float* feat = ar.alloc((size_t)M2 * E);       // enc_norm output = level 0
+    float* pc = ar.alloc((size_t)M2 * D);
+    float* fbuf[4];
+    for (int i = 0; i < 4; i++) fbuf[i] = ar.alloc((size_t)M2 * D);   // ping, pong, hook A, hook B
+    float* dec_last = ar.alloc((size_t)M2 * D);
+    const size_t mark = ar.off;
+    // ---------------- encoder (model.py:151-163)
+    {
+        float* cols = ar.alloc((size_t)M2 * 768);
+        float* x = ar.alloc((size_t)M2 * E);
+        float* xn = ar.alloc((size_t)M2 * E);
+        float* qkv = ar.alloc((size_t)M2 * 3 * E);
+        float* att = ar.alloc((size_t)M2 * E);
+        float* hid = ar.alloc((size_t)M2 * E * c.mlp_ratio);
+        if (!dry) {
+            const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
+            if ((P.rc = a3r_patchify(img1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+            if ((P.rc = a3r_patchify(img2, cols + (size_t)BN * 768, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+        }
+        P.linear(cols, 768, m->pe_w, x, E, M2, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
+        for (int i = 0; i < c.enc_depth; i++) {
+            P.self_block(m->enc[i], x, x, M2, E, c.enc_num_heads, N, nw, E * c.mlp_ratio, xn, qkv, att, hid);
+            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, M2, E, E * c.mlp_ratio, xn, hid);
+        }
+        P.ln(x, m->encn_w, m->encn_b, feat, M2, E);
+        // point-map patch embedding (model.py:244-248); pred_depth is [B,H,W,3]: channel stride 1
+        if (!dry) {
+            const long sb = 3L * H * W, sc = 1, sy = 3L * W, sx = 3;
+            if ((P.rc = a3r_patchify(pd1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+            if ((P.rc = a3r_patchify(pd2, cols + (size_t)BN * 768, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+        }
+        P.linear(cols, 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
+    }
+    ar.off = mark;
+    // ---------------- decoder (model.py:201-233)
+    const int hook_a = c.dec_depth * 2 / 4, hook_b = c.dec_depth * 3 / 4;   // levels 6 and 9 for depth 12
+    const float *lvl_a = nullptr, *lvl_b = nullptr;
+    {
+        const int hidden = D * c.mlp_ratio;
+        float* xn = ar.alloc((size_t)M2 * D);
+        float* yn = ar.alloc((size_t)M2 * D);
+        float* qkv = ar.alloc((size_t)M2 * 3 * D);
+        float* qb = ar.alloc((size_t)M2 * D);
+        float* kv = ar.alloc((size_t)M2 * 2 * D);
+        float* att = ar.alloc((size_t)M2 * D);
+        float* hid = ar.alloc((size_t)M2 * hidden);
+        float* cur = fbuf[0];
+        P.linear(feat, E, m->de_w, cur, D, M2, D, E, P.epi(A3R_EPI_NONE, m->de_b));
+        P.linear(pc, D, m->zc_w[0], cur, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[0], cur));
+        int next_free = 1;
+        const int npc = n_pc_blocks(c);
+        for (int i = 0; i < c.dec_depth; i++) {
+            const int level = i + 1;
+            float* nxt;
+            if (level == hook_a) nxt = fbuf[2];
+            else if (level == hook_b) nxt = fbuf[3];
+            else { nxt = (cur == fbuf[0]) ? fbuf[1] : fbuf[0]; }
+            (void)next_free;
+            for (int s = 0; s < 2; s++) {
+                const BlockW& w = s ? m->dec2[i] : m->dec1[i];
+                const float* x_in = cur + (size_t)s * BN * D;
+                const float* y_in = cur + (size_t)(1 - s) * BN * D;
+                float* x_out = nxt + (size_t)s * BN * D;
+                float* xn_s = xn + (size_t)s * BN * D;
+                float* yn_s = yn + (size_t)s * BN * D;
+                float* qkv_s = qkv + (size_t)s * BN * 3 * D;
+                float* q_s = qb + (size_t)s * BN * D;
+                float* kv_s = kv + (size_t)s * BN * 2 * D;
+                float* att_s = att + (size_t)s * BN * D;
+                float* hid_s = hid + (size_t)s * BN * hidden;
+                // x = x + attn(norm1(x))                                   blocks.py:187
+                P.self_block(w, x_out, x_in, BN, D, c.dec_num_heads, N, nw, hidden, xn_s, qkv_s, att_s, hid_s);
+                // y_ = norm_y(y); x = x + cross_attn(norm2(x), y_, y_)     blocks.py:188-189
+                P.ln(y_in, w.nyw, w.nyb, yn_s, BN, D);
+                P.ln(x_out, w.n2w, w.n2b, xn_s, BN, D);
+                P.linear(xn_s, D, w.qw, q_s, D, BN, D, D, P.rope_epi(w.qb, D, N, nw));
+                P.linear(yn_s, D, w.kvw, kv_s, 2 * D, BN, 2 * D, D, P.rope_epi(w.kvb, D, N, nw));
+                P.attn(q_s, D, kv_s, 2 * D, kv_s + D, 2 * D, att_s, D, B, c.dec_num_heads, N, N);
+                P.linear(att_s, D, w.cprojw, x_out, D, BN, D, D, P.epi(A3R_EPI_RESID, w.cprojb, x_out));
+                // x = x + mlp(norm3(x))                                    blocks.py:190
+                P.mlp(w, w.n3w, w.n3b, x_out, BN, D, hidden, xn_s, hid_s);
+            }
+            if (i < npc) {   // model.py:223-226
+                P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, hidden, xn, qkv, att, hid);
+                P.mlp(m->pc[i], m->pc[i].n2w, m->pc[i].n2b, pc, M2, D, hidden, xn, hid);
+                P.linear(pc, D, m->zc_w[i + 1], nxt, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[i + 1], nxt));
+            }
+            if (level == hook_a) lvl_a = nxt;
+            if (level == hook_b) lvl_b = nxt;
+            cur = nxt;
+        }
+        P.ln(cur, m->decn_w, m->decn_b, dec_last, M2, D);   // model.py:231-232
+    }
+    ar.off = mark;
+    if (!dry) {
+        m->taps.clear();
+        m->taps["feat"] = {feat, (size_t)M2 * E};
+        m->taps["hook_a"] = {lvl_a, (size_t)M2 * D};
+        m->taps["hook_b"] = {lvl_b, (size_t)M2 * D};
+        m->taps["dec_last"] = {dec_last, (size_t)M2 * D};
+    }
+    // ---------------- DPT heads (dpt_head.py:34-66), one per view, fp32
+    for (int s = 0; s < 2; s++) {
+        ar.off = mark;
+        const HeadW& Hd = m->head[s];
+        const int* ld = c.layer_dims;
+        const float* t0 = feat + (size_t)s * BN * E;
+        const float* t1 = lvl_a + (dry ? 0 : (size_t)s * BN * D);
+        const float* t2 = lvl_b + (dry ? 0 : (size_t)s * BN * D);
+        const float* t3 = dec_last + (size_t)s * BN * D;
+        const int h3 = (nh + 2 - 3) / 2 + 1, w3 = (nw + 2 - 3) / 2 + 1;
+        // act_postprocess (dpt_block.py:353-405)
+        float* a0 = ar.alloc((size_t)BN * ld[0]);
+        P.linear(t0, E, Hd.a0w, a0, ld[0], BN, ld[0], E, P.epi(A3R_EPI_NONE, Hd.a0b));
+        float* l0 = ar.alloc((size_t)BN * 16 * ld[0]);
+        {
+            a3r_epilogue e = P.epi(A3R_EPI_PIXSHUF, Hd.a0tb);
+            e.ps_s = 4; e.ps_h = nh; e.ps_w = nw; e.ps_cout = ld[0];
+            P.linear(a0, ld[0], Hd.a0tw, l0, ld[0], BN, 16 * ld[0], ld[0], e);
+        }
+        float* a1 = ar.alloc((size_t)BN * ld[1]);
+        P.linear(t1, D, Hd.a1w, a1, ld[1], BN, ld[1], D, P.epi(A3R_EPI_NONE, Hd.a1b));
+        float* l1 = ar.alloc((size_t)BN * 4 * ld[1]);
+        {
+            a3r_epilogue e = P.epi(A3R_EPI_PIXSHUF, Hd.a1tb);
+            e.ps_s = 2; e.ps_h = nh; e.ps_w = nw; e.ps_cout = ld[1];
+            P.linear(a1, ld[1], Hd.a1tw, l1, ld[1], BN, 4 * ld[1], ld[1], e);
+        }
+        float* l2 = ar.alloc((size_t)BN * ld[2]);
+        P.linear(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
+        float* a3 = ar.alloc((size_t)BN * ld[3]);
+        P.linear(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
+        float* l3 = ar.alloc((size_t)B * h3 * w3 * ld[3]);
+        P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
+        // scratch.layer_rn (no bias)
+        float* r0 = ar.alloc((size_t)BN * 16 * F);
+        P.conv(l0, Hd.rn[0], r0, B, 4 * nh, 4 * nw, ld[0], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+        float* r1 = ar.alloc((size_t)BN * 4 * F);
+        P.conv(l1, Hd.rn[1], r1, B, 2 * nh, 2 * nw, ld[1], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+        float* r2 = ar.alloc((size_t)BN * F);
+        P.conv(l2, Hd.rn[2], r2, B, nh, nw, ld[2], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+        float* r3 = ar.alloc((size_t)B * h3 * w3 * F);
+        P.conv(l3, Hd.rn[3], r3, B, h3, w3, ld[3], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+        // refinement (dpt_head.py:57-60)
+        float* p4 = fusion(P, Hd.ref[3], r3, nullptr, false, B, h3, w3, F, nh, nw);
+        float* p3 = fusion(P, Hd.ref[2], p4, r2, true, B, nh, nw, F, 2 * nh, 2 * nw);
+        float* p2 = fusion(P, Hd.ref[1], p3, r1, true, B, 2 * nh, 2 * nw, F, 4 * nh, 4 * nw);
+        float* p1 = fusion(P, Hd.ref[0], p2, r0, true, B, 4 * nh, 4 * nw, F, 8 * nh, 8 * nw);
+        // head (dpt_block.py:323-330)
+        const int Hh = 8 * nh, Wh = 8 * nw;
+        float* h0 = ar.alloc((size_t)B * Hh * Wh * (F / 2));
+        P.conv(p1, Hd.h0w, h0, B, Hh, Wh, F, F / 2, 1, P.epi(A3R_EPI_NONE, Hd.h0b));
+        float* hu = ar.alloc((size_t)B * H * W * (F / 2));
+        P.up(h0, hu, B, Hh, Wh, F / 2, H, W);
+        float* h2 = ar.alloc((size_t)B * H * W * L);
+        P.conv(hu, Hd.h2w, h2, B, H, W, F / 2, L, 1, P.epi(A3R_EPI_RELU, Hd.h2b));
+        if (!P.skip())
+            P.rc = a3r_head_final(h2, Hd.h4w, Hd.h4b, s ? pts2 : pts1, s ? conf2 : conf1, (long)B * H * W, L, stream);
+    }
+    if (peak) *peak = ar.peak;
+    return P.rc;
+}
+}  // namespace
+
+extern "C" size_t a3r_model_workspace_bytes(a3r_model_t m, int B, int H, int W) {
+    if (!m || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return 0;
+    size_t peak = 0;
+    run_plan(m, true, nullptr, nullptr, nullptr, nullptr, B, H, W, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &peak);
+    return peak;
+}
+
+extern "C" int a3r_model_forward(a3r_model_t m, const float* img1, const float* img2, const float* pd1, const float* pd2,
+                                 int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    A3R_CHECK_ARG(m, "a3r_model_forward: null handle");
+    if (!m->finalized) {
+        set_error("a3r_model_forward: a3r_model_finalize has not been called");
+        return A3R_ESTATE;
+    }
+    A3R_CHECK_ARG(img1 && img2 && pd1 && pd2 && pts1 && conf1 && pts2 && conf2 && workspace, "a3r_model_forward: null pointer");
+    A3R_CHECK_ARG(B > 0, "a3r_model_forward: batch must be positive");
+    A3R_CHECK_ARG(H > 0 && H % 16 == 0, "Input image height (%d) is not a multiple of patch size (16).", H);
+    A3R_CHECK_ARG(W > 0 && W % 16 == 0, "Input image width (%d) is not a multiple of patch size (16).", W);
+    A3R_CHECK_ARG(H / 16 < a3r_model_s::MAX_POS && W / 16 < a3r_model_s::MAX_POS, "a3r_model_forward: image too large for the RoPE table");
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "a3r_model_forward: workspace must be 256-byte aligned");
+    const size_t need_bytes = a3r_model_workspace_bytes(m, B, H, W);
+    A3R_CHECK_ARG(workspace_bytes >= need_bytes, "a3r_model_forward: workspace too small (%zu < %zu)", workspace_bytes, need_bytes);
+    return run_plan(m, false, img1, img2, pd1, pd2, B, H, W, pts1, conf1, pts2, conf2, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count) {
+    A3R_CHECK_ARG(m && name && ptr && count, "a3r_model_tap: null argument");
+    auto it = m->taps.find(name);
+    A3R_CHECK_ARG(it != m->taps.end(), "a3r_model_tap: unknown tap '%s' (run a forward first)", name);
+    *ptr = it->second.first;
+    *count = it->second.second;
+    return A3R_OK;
+}

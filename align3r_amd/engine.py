@@ -1,0 +1,90 @@
+"""PairEngine: owner of one a3r_model handle (the HIP pair forward) on one GPU.
+
+Host-side plumbing only: keeps the checkpoint tensors alive on the device, hands their pointers to
+liba3r (a3r_model_set_weight), provides the packed-weight and workspace buffers, and calls
+a3r_model_forward.  Mirrors what AsymmetricCroCo3DStereo.forward returns (dust3r/model.py:241-257).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ModelConfigC, check, ptr, stream_ptr
+from .weights import ModelConfig, param_spec
+
+
+class PairEngine:
+    def __init__(self, cfg: ModelConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0"):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("PairEngine needs a HIP device (there is no CPU fallback)")
+        c = ModelConfigC(cfg.enc_embed_dim, cfg.enc_depth, cfg.enc_num_heads, cfg.dec_embed_dim, cfg.dec_depth,
+                         cfg.dec_num_heads, cfg.mlp_ratio, cfg.patch_size, cfg.rope_base, cfg.feature_dim, cfg.last_dim,
+                         (C.c_int * 4)(*cfg.layer_dims))
+        self.handle = C.c_void_p()
+        check(self.lib.a3r_model_create(C.byref(c), C.byref(self.handle)), "a3r_model_create")
+        self.weights = {}
+        with torch.cuda.device(self.device):
+            for name, shape, _ in param_spec(cfg):
+                if name not in state_dict:
+                    raise RuntimeError(f"missing weight '{name}' in state_dict")
+                t = state_dict[name]
+                t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t
+                t = t.detach().to(self.device, torch.float32).contiguous()
+                if tuple(t.shape) != tuple(shape):
+                    raise RuntimeError(f"size mismatch for {name}: {tuple(t.shape)} vs {tuple(shape)}")
+                self.weights[name] = t
+                shp = (C.c_int64 * t.dim())(*t.shape)
+                check(self.lib.a3r_model_set_weight(self.handle, name.encode(), ptr(t), t.dim(), shp), name)
+            nbytes = self.lib.a3r_model_packed_bytes(self.handle)
+            self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            check(self.lib.a3r_model_finalize(self.handle, ptr(self.packed), nbytes, stream_ptr()), "a3r_model_finalize")
+            torch.cuda.current_stream().synchronize()
+        self.workspace = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.a3r_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace_bytes(self, B, H, W):
+        return int(self.lib.a3r_model_workspace_bytes(self.handle, B, H, W))
+
+    def forward(self, img1, img2, pd1, pd2, out=None):
+        """img* [B,3,H,W], pd* [B,H,W,3] (device fp32) -> dict(pts3d_1, conf_1, pts3d_2, conf_2)."""
+        B, _, H, W = img1.shape
+        for t, shp, nm in ((img1, (B, 3, H, W), "img1"), (img2, (B, 3, H, W), "img2"), (pd1, (B, H, W, 3), "pred_depth1"),
+                           (pd2, (B, H, W, 3), "pred_depth2")):
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise RuntimeError(f"{nm}: expected contiguous float32 {shp} on {self.device}, got {tuple(t.shape)} {t.dtype} {t.device}")
+        with torch.cuda.device(self.device):
+            need = self.workspace_bytes(B, H, W)
+            if need == 0:
+                raise RuntimeError(f"Input image size ({H}x{W}) is not a multiple of patch size (16).")
+            if self.workspace is None or self.workspace.numel() < need:
+                self.workspace = None
+                self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if out is None:
+                out = dict(pts3d_1=torch.empty((B, H, W, 3), device=self.device), conf_1=torch.empty((B, H, W), device=self.device),
+                           pts3d_2=torch.empty((B, H, W, 3), device=self.device), conf_2=torch.empty((B, H, W), device=self.device))
+            check(self.lib.a3r_model_forward(self.handle, ptr(img1), ptr(img2), ptr(pd1), ptr(pd2), B, H, W,
+                                             ptr(out["pts3d_1"]), ptr(out["conf_1"]), ptr(out["pts3d_2"]), ptr(out["conf_2"]),
+                                             ptr(self.workspace), self.workspace.numel(), stream_ptr()), "a3r_model_forward")
+        return out
+
+    def tap(self, name, cols):
+        """Intermediate tensor of the last forward as a [rows, cols] view of the workspace (parity tests)."""
+        p = C.c_void_p()
+        n = C.c_size_t()
+        check(self.lib.a3r_model_tap(self.handle, name.encode(), C.byref(p), C.byref(n)), "a3r_model_tap")
+        off = p.value - self.workspace.data_ptr()
+        return self.workspace[off:off + n.value * 4].view(torch.float32).view(-1, cols)

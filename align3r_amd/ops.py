@@ -1,0 +1,178 @@
+"""Operator-level Python entry points over the C ABI (torch CUDA tensors are containers only).
+
+Each function names the reference op it stands in for; argument meaning and error behaviour follow
+that op.  Tensors must be fp32, contiguous (unless a stride argument exists) and on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Epilogue, check, ptr, stream_ptr
+
+_ROPE_CACHE = {}
+
+
+def _req(t: torch.Tensor, name: str):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name} must be a contiguous float32 CUDA tensor")
+    return t
+
+
+def rope_tables(device, base: float = 100.0, max_pos: int = 256):
+    """cos/sin [max_pos, 16] on `device`, computed by the library like RoPE2D.get_cos_sin (pos_embed.py:118-128)."""
+    key = (str(device), float(base), max_pos)
+    if key not in _ROPE_CACHE:
+        cos = np.empty((max_pos, 16), np.float32)
+        sin = np.empty((max_pos, 16), np.float32)
+        check(_lib.load().a3r_rope_table_host(cos.ctypes.data_as(C.c_void_p), sin.ctypes.data_as(C.c_void_p), max_pos, base))
+        _ROPE_CACHE[key] = (torch.from_numpy(cos).to(device), torch.from_numpy(sin).to(device))
+    return _ROPE_CACHE[key]
+
+
+def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float = 1.0):
+    """curope.rope_2d(tokens[B,N,H,D], positions[B,N,2] int64, base, fwd): in place (curope.cpp:49-65)."""
+    if tokens.dim() != 4:
+        raise RuntimeError("tokens must have 4 dimensions")
+    if positions.dim() != 3:
+        raise RuntimeError("positions must have 3 dimensions")
+    if tokens.size(0) != positions.size(0):
+        raise RuntimeError("batch size differs between tokens & positions")
+    if tokens.size(1) != positions.size(1):
+        raise RuntimeError("seq_length differs between tokens & positions")
+    if positions.size(2) != 2:
+        raise RuntimeError("positions.shape[2] must be equal to 2")
+    if tokens.is_cuda != positions.is_cuda:
+        raise RuntimeError("tokens and positions are not on the same device")
+    _req(tokens, "tokens")
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("positions must be a contiguous int64 tensor")
+    B, N, H, D = tokens.shape
+    check(_lib.load().a3r_rope2d(ptr(tokens), ptr(positions), B, N, H, D, base, fwd, stream_ptr()), "rope_2d")
+    return tokens
+
+
+def layernorm(x, w, b, eps=1e-6, out=None):
+    """nn.LayerNorm over the last dim."""
+    _req(x, "x")
+    D = x.shape[-1]
+    M = x.numel() // D
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().a3r_layernorm(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(out), M, D, eps, stream_ptr()), "layernorm")
+    return out
+
+
+def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None):
+    e = Epilogue()
+    e.epi = kind
+    e.bias = None if bias is None else bias.data_ptr()
+    e.resid = None if resid is None else resid.data_ptr()
+    e.resid2 = None if resid2 is None else resid2.data_ptr()
+    e.relu_a = int(relu_a)
+    if rope is not None:
+        e.rope_cols, e.tokens_per_image, e.grid_w, cos, sin = rope
+        e.rope_cos, e.rope_sin = cos.data_ptr(), sin.data_ptr()
+    if pixshuf is not None:
+        e.ps_s, e.ps_h, e.ps_w, e.ps_cout = pixshuf
+    return e
+
+
+def linear(x, w, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
+    """nn.Linear on x [..., K] with w [N, K] (+ fused epilogue, see include/a3r.h)."""
+    _req(x, "x"); _req(w, "w")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+    e = make_epilogue(epi, bias, **kw)
+    check(_lib.load().a3r_linear(ptr(x), K, ptr(w), ptr(out), out.shape[-1] if epi != _lib.EPI_PIXSHUF else e.ps_cout,
+                                 M, N, K, C.byref(e), stream_ptr()), "linear")
+    return out
+
+
+def pack_conv3x3(w):
+    Cout, Cin = w.shape[:2]
+    wp = torch.empty((Cout, 3, 3, Cin), device=w.device, dtype=torch.float32)
+    check(_lib.load().a3r_pack_conv3x3(ptr(_req(w, "w")), ptr(wp), Cout, Cin, stream_ptr()))
+    return wp
+
+
+def pack_convT(w):
+    Cin, Cout, s, _ = w.shape
+    wp = torch.empty((s * s * Cout, Cin), device=w.device, dtype=torch.float32)
+    check(_lib.load().a3r_pack_convT(ptr(_req(w, "w")), ptr(wp), Cin, Cout, s, stream_ptr()))
+    return wp
+
+
+def conv3x3(x, wp, bias=None, stride=1, epi=_lib.EPI_NONE, **kw):
+    """nn.Conv2d(k=3, padding=1, stride) on channels-last x [B,H,W,Cin] with packed weights [Cout,3,3,Cin]."""
+    _req(x, "x"); _req(wp, "wp")
+    B, H, W, Cin = x.shape
+    Cout = wp.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    e = make_epilogue(epi, bias, **kw)
+    check(_lib.load().a3r_conv3x3(ptr(x), ptr(wp), ptr(out), B, H, W, Cin, Cout, stride, C.byref(e), stream_ptr()), "conv3x3")
+    return out
+
+
+def conv_transpose(x, wpT, bias, s):
+    """nn.ConvTranspose2d(kernel=stride=s) on channels-last x [B,H,W,Cin] with a3r_pack_convT weights."""
+    B, H, W, Cin = x.shape
+    Cout = wpT.shape[0] // (s * s)
+    out = torch.empty((B, H * s, W * s, Cout), device=x.device, dtype=torch.float32)
+    linear(x.reshape(B * H * W, Cin), wpT, bias, epi=_lib.EPI_PIXSHUF, out=out, pixshuf=(s, H, W, Cout))
+    return out
+
+
+def attention(q, k, v, H):
+    """softmax(q k^T / 8) v for head_dim 64; q [B,Nq,H*64], k/v [B,Nk,H*64] (may be column slices of a wider buffer)."""
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise RuntimeError("attention operands must be row-strided views [B, N, ld]")
+    o = torch.empty((B, Nq, H * 64), device=q.device, dtype=torch.float32)
+    check(_lib.load().a3r_attention(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), H * 64, B, H, Nq, Nk,
+                                    stream_ptr()), "attention")
+    return o
+
+
+def patchify(img, channels_last=False):
+    """im2col of the 16x16/stride-16 patch embedding; img [B,3,H,W] (or [B,H,W,3] if channels_last)."""
+    _req(img, "img")
+    if channels_last:
+        B, H, W, Cc = img.shape
+        strides = (H * W * Cc, 1, W * Cc, Cc)
+    else:
+        B, Cc, H, W = img.shape
+        strides = (Cc * H * W, H * W, W, 1)
+    cols = torch.empty((B * (H // 16) * (W // 16), Cc * 256), device=img.device, dtype=torch.float32)
+    check(_lib.load().a3r_patchify(ptr(img), ptr(cols), B, Cc, H, W, *strides, stream_ptr()), "patchify")
+    return cols
+
+
+def upsample2x(x, crop=None):
+    """F.interpolate(scale_factor=2, bilinear, align_corners=True) on channels-last [B,H,W,C]."""
+    _req(x, "x")
+    B, H, W, Cc = x.shape
+    Hc, Wc = crop if crop else (2 * H, 2 * W)
+    out = torch.empty((B, Hc, Wc, Cc), device=x.device, dtype=torch.float32)
+    check(_lib.load().a3r_upsample2x(ptr(x), ptr(out), B, H, W, Cc, Hc, Wc, stream_ptr()), "upsample2x")
+    return out
+
+
+def head_final(x, w, b):
+    """conv1x1 (C -> 4) + postprocess (postprocess.py:10-58) on channels-last x [..., C]."""
+    _req(x, "x")
+    Cc = x.shape[-1]
+    P = x.numel() // Cc
+    pts = torch.empty(x.shape[:-1] + (3,), device=x.device, dtype=torch.float32)
+    conf = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    check(_lib.load().a3r_head_final(ptr(x), ptr(_req(w.reshape(4, Cc), "w")), ptr(_req(b, "b")), ptr(pts), ptr(conf), P, Cc,
+                                     stream_ptr()), "head_final")
+    return pts, conf

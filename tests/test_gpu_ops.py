@@ -1,0 +1,175 @@
+"""GPU: each HIP operator (through the C ABI) against a plain PyTorch fp32 reference of the same op and
+against the numpy oracle on the reference-generated goldens.  Tolerance: 2e-5 x tensor max for single
+ops (fp32 products, different summation order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from align3r_amd import ops as O
+    return O
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 96, 96), (1536, 3072, 1024), (77, 300, 768), (768, 4096, 1024)])
+def test_linear_plain_bias(ops, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = ops.linear(x, w, b)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert rel_err(cpu(y), cpu(ref)) < TOL
+
+
+def test_linear_epilogues(ops):
+    from align3r_amd import _lib
+    M, N, K = 300, 256, 128
+    x, w, b, r, r2 = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    lin = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert rel_err(cpu(ops.linear(x, w, b, epi=_lib.EPI_GELU)), cpu(torch.nn.functional.gelu(lin))) < TOL
+    assert rel_err(cpu(ops.linear(x, w, b, epi=_lib.EPI_RELU)), cpu(torch.relu(lin))) < TOL
+    assert rel_err(cpu(ops.linear(x, w, b, epi=_lib.EPI_RESID, resid=r)), cpu(lin + r.double())) < TOL
+    assert rel_err(cpu(ops.linear(x, w, b, epi=_lib.EPI_RESID2, resid=r, resid2=r2)), cpu(lin + r.double() + r2.double())) < TOL
+    out = r.clone()      # in-place residual (resid aliases the output)
+    ops.linear(x, w, b, epi=_lib.EPI_RESID, resid=out, out=out)
+    assert rel_err(cpu(out), cpu(lin + r.double())) < TOL
+    assert rel_err(cpu(ops.linear(x, w, None, relu_a=True)), cpu(torch.nn.functional.linear(torch.relu(x).double(), w.double()))) < TOL
+
+
+def test_linear_rope_epilogue_matches_reference_rope(ops):
+    """qkv projection + fused RoPE == Linear then RoPE2D (goldens from the reference's RoPE2D)."""
+    from align3r_amd import _lib
+    from oracle import model_np as O
+    B, gh, gw, H = 2, 5, 7, 3
+    N, D = gh * gw, H * 64
+    x = rnd(B * N, D, seed=1)
+    w, b = rnd(3 * D, D, seed=2, scale=D ** -0.5), rnd(3 * D, seed=3)
+    cos, sin = ops.rope_tables(x.device)
+    y = ops.linear(x, w, b, epi=_lib.EPI_ROPE, rope=(2 * D, N, gw, cos, sin))
+    lin = cpu(torch.nn.functional.linear(x.double(), w.double(), b.double())).astype(np.float32).reshape(B, N, 3, H, 64)
+    pos = O.positions(B, gh, gw)
+    q = O.rope2d(lin[:, :, 0].transpose(0, 2, 1, 3), pos).transpose(0, 2, 1, 3)
+    k = O.rope2d(lin[:, :, 1].transpose(0, 2, 1, 3), pos).transpose(0, 2, 1, 3)
+    ref = np.stack([q, k, lin[:, :, 2]], 2).reshape(B * N, 3 * D)
+    assert rel_err(cpu(y), ref) < TOL
+
+
+def test_rope2d_standalone_vs_golden(ops):
+    g = np.load(os.path.join(GOLDEN, "ops.npz"))
+    tok = torch.from_numpy(g["rope_tok"]).cuda().transpose(1, 2).contiguous()     # [B,N,H,D] as curope sees it
+    pos = torch.from_numpy(g["rope_pos"]).cuda()
+    ops.rope_2d(tok, pos, 100.0, 1.0)
+    assert rel_err(cpu(tok.transpose(1, 2)), g["rope_out"]) < TOL
+    ops.rope_2d(tok, pos, 100.0, -1.0)        # backward pass of the reference = same kernel with fwd = -1
+    assert rel_err(cpu(tok.transpose(1, 2)), g["rope_tok"]) < TOL
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(tok[0], pos, 100.0)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(tok, pos[:1], 100.0)
+
+
+@pytest.mark.parametrize("M,D", [(10, 1024), (333, 768), (5, 128), (64, 256)])
+def test_layernorm(ops, M, D):
+    x, w, b = rnd(M, D, seed=1, scale=3.0) + 0.5, rnd(D, seed=2), rnd(D, seed=3)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+    assert rel_err(cpu(ops.layernorm(x, w, b)), cpu(ref)) < TOL
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 32, 64), (2, 3, 196, 196), (1, 2, 768, 768), (2, 2, 100, 37), (1, 12, 576, 576)])
+def test_attention(ops, B, H, Nq, Nk):
+    q, k, v = rnd(B, Nq, H * 64, seed=1), rnd(B, Nk, H * 64, seed=2), rnd(B, Nk, H * 64, seed=3)
+    o = ops.attention(q, k, v, H)
+    qh, kh, vh = (t.double().reshape(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(B, Nq, H * 64)
+    assert rel_err(cpu(o), cpu(ref)) < TOL
+
+
+def test_attention_fused_qkv_layout_and_spike(ops):
+    """q/k/v as column slices of one [B,N,3D] buffer; one key spiked so the running max jumps mid-sequence."""
+    B, H, N = 1, 2, 300
+    qkv = rnd(B, N, 3 * H * 64, seed=5)
+    qkv[0, 200, H * 64:2 * H * 64] *= 30.0
+    D = H * 64
+    o = ops.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H)
+    qh, kh, vh = (qkv[:, :, i * D:(i + 1) * D].double().reshape(B, N, H, 64).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(B, N, D)
+    assert rel_err(cpu(o), cpu(ref)) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(1, 8, 8, 32, 32, 1), (2, 13, 9, 96, 256, 1), (1, 24, 32, 64, 64, 2),
+                                                  (1, 5, 7, 128, 96, 2), (1, 48, 64, 256, 128, 1)])
+def test_conv3x3(ops, B, H, W, Cin, Cout, stride):
+    from align3r_amd import _lib
+    x = rnd(B, H, W, Cin, seed=1)
+    w, b = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=3)
+    y = ops.conv3x3(x, ops.pack_conv3x3(w), b, stride=stride)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(cpu(y), cpu(ref)) < TOL
+    if stride == 1 and Cin == Cout:       # RCU pattern: relu on load, relu epilogue, two residuals
+        r2 = rnd(B, H, W, Cout, seed=4)
+        y = ops.conv3x3(x, ops.pack_conv3x3(w), b, epi=_lib.EPI_RESID2, resid=x, resid2=r2, relu_a=True)
+        ref = torch.nn.functional.conv2d(torch.relu(x).double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) \
+            + x.double() + r2.double()
+        assert rel_err(cpu(y), cpu(ref)) < TOL
+
+
+@pytest.mark.parametrize("s,C", [(4, 96), (2, 192)])
+def test_conv_transpose(ops, s, C):
+    x = rnd(2, 3, 5, C, seed=1)
+    w, b = rnd(C, C, s, s, seed=2, scale=C ** -0.5), rnd(C, seed=3)
+    y = ops.conv_transpose(x, ops.pack_convT(w), b, s)
+    ref = torch.nn.functional.conv_transpose2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=s).permute(0, 2, 3, 1)
+    assert rel_err(cpu(y), cpu(ref)) < TOL
+
+
+def test_upsample_postprocess_patchify_vs_goldens(ops):
+    g = np.load(os.path.join(GOLDEN, "ops.npz"))
+    up_x = np.ascontiguousarray(np.pad(g["up_x"], ((0, 0), (0, 2), (0, 0), (0, 0))).transpose(0, 2, 3, 1))  # C 6 -> 8
+    y = ops.upsample2x(torch.from_numpy(up_x).cuda())
+    assert rel_err(cpu(y)[..., :6], g["up_out"].transpose(0, 2, 3, 1)) < TOL
+    yc = ops.upsample2x(torch.from_numpy(up_x).cuda(), crop=(13, 9))
+    assert np.array_equal(cpu(yc), cpu(y)[:, :13, :9])
+    # head_final with an identity 4x4 "conv" reproduces postprocess() on the golden map
+    f = np.ascontiguousarray(g["pp_x"].transpose(0, 2, 3, 1))
+    pts, conf = ops.head_final(torch.from_numpy(f).cuda(), torch.eye(4).cuda(), torch.zeros(4).cuda())
+    assert rel_err(cpu(pts), g["pp_pts3d"]) < TOL and rel_err(cpu(conf), g["pp_conf"]) < TOL
+    assert np.all(cpu(pts)[0, 0, 0] == 0)
+    x = rnd(2, 3, 32, 48, seed=3)
+    cols = ops.patchify(x)
+    ref = x.reshape(2, 3, 2, 16, 3, 16).permute(0, 2, 4, 1, 3, 5).reshape(12, 768)
+    assert torch.equal(cols, ref)
+    cols2 = ops.patchify(x.permute(0, 2, 3, 1).contiguous(), channels_last=True)
+    assert torch.equal(cols2, ref)
+    with pytest.raises(RuntimeError, match="not a multiple of patch size"):
+        ops.patchify(rnd(1, 3, 30, 48))
+
+
+def test_head_final_128(ops):
+    x, w, b = rnd(3, 17, 19, 128, seed=1), rnd(4, 128, 1, 1, seed=2, scale=0.05), rnd(4, seed=3, scale=0.1)
+    pts, conf = ops.head_final(x, w, b)
+    f = torch.nn.functional.linear(x.double(), w.double().reshape(4, 128), b.double())
+    d = f[..., :3].norm(dim=-1, keepdim=True)
+    assert rel_err(cpu(pts), cpu(f[..., :3] / d.clip(min=1e-8) * torch.expm1(d))) < TOL
+    assert rel_err(cpu(conf), cpu(1 + f[..., 3].exp())) < TOL
+
+
+def test_errors_are_loud(ops):
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.linear(rnd(4, 40), rnd(8, 40))
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 32), rnd(8, 32))      # CPU tensor
