@@ -50,6 +50,9 @@ SIGNATURES = {
     "a3r_last_error": (C.c_char_p, []),
     "a3r_version": (C.c_int, []),
     "a3r_device_count": (C.c_int, []),
+    "a3r_prof_enable": (C.c_int, [C.c_int]),
+    "a3r_prof_kernel_count": (C.c_int, []),
+    "a3r_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "a3r_rope2d": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_void]),
     "a3r_layernorm": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
     "a3r_linear": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
@@ -115,3 +118,18 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def prof_enable(on: bool):
+    check(load().a3r_prof_enable(int(on)))
+
+
+def prof_report():
+    """[{name, launches, ms, work}] per kernel class, from the HIP events recorded since prof_enable(True)."""
+    lib = load()
+    out = []
+    for k in range(lib.a3r_prof_kernel_count()):
+        name, n, ms, work = C.c_char_p(), C.c_long(), C.c_double(), C.c_double()
+        check(lib.a3r_prof_get(k, C.byref(name), C.byref(n), C.byref(ms), C.byref(work)))
+        out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, work=work.value))
+    return out

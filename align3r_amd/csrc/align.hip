@@ -563,6 +563,9 @@ extern "C" int a3r_align_destroy(a3r_align_t a) {
 template <int MODE>
 static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, hipStream_t st) {
     dim3 grid(a->d.nchunks, a->d.N), block(TPB);
+    // algorithmic bytes of one iteration: 32 B per edge-pixel + 24 B per image-pixel (+4 mono)
+    const double bytes = 32.0 * a->d.E * a->d.P + (MODE == 2 ? 24.0 : 4.0) * a->d.N * a->d.P + (a->use_mono ? 4.0 * a->d.N * a->d.P : 0.0);
+    ProfScope prof(PK_ALIGN_MAIN, bytes, st);
     if (a->use_mono) {
         if (a->dist_l2) hipLaunchKernelGGL((align_main_kernel<true, true, MODE>), grid, block, 0, st, a->d, ad, g_depth);
         else hipLaunchKernelGGL((align_main_kernel<true, false, MODE>), grid, block, 0, st, a->d, ad, g_depth);
@@ -584,8 +587,11 @@ extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {
     ad.step = a->steps;
     refresh_if_dirty(a, st);
     launch_main<2>(a, ad, nullptr, st);
-    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
-    hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, nullptr);
+    {
+        ProfScope prof(PK_ALIGN_SMALL, 0.0, st);
+        hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
+        hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, nullptr);
+    }
     A3R_LAUNCH_CHECK();
     a->steps++;
     return A3R_OK;

@@ -186,6 +186,7 @@ extern "C" int a3r_attention(const float* q, int ldq, const float* k, int ldk, c
     }
     AttnArgs a = {q, k, v, o, ldq, ldk, ldv, ldo, B, H, Nq, Nk};
     dim3 grid((Nq + AQ - 1) / AQ, H, B);
+    ProfScope prof(PK_ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), ATTN_LDS_BYTES, as_stream(stream), a);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -36,6 +36,17 @@ void set_error(const char* fmt, ...);
         }                                                                                       \
     } while (0)
 
+// ---- optional per-kernel timing with HIP events on the launch stream (a3r_prof_* in include/a3r.h)
+enum ProfKernel { PK_LINEAR = 0, PK_CONV, PK_ATTENTION, PK_LAYERNORM, PK_ELEMENTWISE, PK_ALIGN_MAIN, PK_ALIGN_SMALL, PK_COUNT };
+bool prof_enabled();
+void prof_begin(int kernel, double work, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(int kernel, double work, hipStream_t s) : st(s), on(prof_enabled()) { if (on) prof_begin(kernel, work, st); }
+    ~ProfScope() { if (on) prof_end(st); }
+};
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -194,6 +194,7 @@ extern "C" int a3r_layernorm(const float* x, const float* w, const float* b, flo
     A3R_CHECK_ARG(x && w && b && y, "a3r_layernorm: null pointer");
     A3R_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0, "a3r_layernorm: bad shape M=%d D=%d", M, D);
     hipStream_t st = as_stream(stream);
+    ProfScope prof(PK_LAYERNORM, 8.0 * M * D, st);
     dim3 grid((M + 3) / 4), block(256);
     if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, w, b, y, M, D, eps);
     else if (D == 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps);
@@ -238,6 +239,7 @@ extern "C" int a3r_patchify(const float* img, float* cols, int B, int C, int H, 
     A3R_CHECK_ARG(H > 0 && H % 16 == 0, "Input image height (%d) is not a multiple of patch size (16).", H);
     A3R_CHECK_ARG(W > 0 && W % 16 == 0, "Input image width (%d) is not a multiple of patch size (16).", W);
     const long total = (long)B * (H / 16) * (W / 16) * C * 256;
+    ProfScope prof(PK_ELEMENTWISE, 8.0 * total, as_stream(stream));
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), img, cols, B, C, H, W, sb, sc,
                        sy, sx);
     A3R_LAUNCH_CHECK();
@@ -249,6 +251,7 @@ extern "C" int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int
     A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "a3r_upsample2x: bad shape");
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
+    ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
@@ -260,6 +263,7 @@ extern "C" int a3r_head_final(const float* x, const float* w, const float* b, fl
     A3R_CHECK_ARG(P > 0 && C > 0 && C % 4 == 0, "a3r_head_final: bad shape");
     long blocks = (P + 7) / 8;
     if (blocks > 16384) blocks = 16384;
+    ProfScope prof(PK_ELEMENTWISE, 4.0 * P * (C + 4), as_stream(stream));
     hipLaunchKernelGGL(head_final_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, w, b, pts3d, conf, P, C);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -206,6 +206,7 @@ static int launch_gemm(int amode, GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     const int nwg = g.tiles_m * g.tiles_n;
+    ProfScope prof(amode == 0 ? PK_LINEAR : PK_CONV, 2.0 * g.M * g.N * g.K, st);
     if (amode == 0) {
         if (!attr_done[0]) {
             A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<0>),

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/s of the HIP pair forward (+ global-alignment iters/s) on N MI355X.
+
+Contract (one JSON line on rank 0):
+  metric  = BASELINE.json's "frame-pairs/s ViT-L 512px + global-align iters/s"
+  value   = frame-pairs/s, whole job (all ranks), inputs resident in HBM when the timed region starts
+  a step  = one batch of --batch frame pairs of the 16-frame 512x384 synthetic clip (BASELINE config 2:
+            ViT-L, swin-3-noncyclic symmetrised pair graph, E = 84) through a3r_model_forward;
+            for N > 1 every rank runs its own K steps (weak scaling: pairs shard with no data-path
+            dependency) and each step ends with ONE RCCL all-gather of the step's pointmaps+confidences,
+            the exchange that assembles the aligner input.
+  extra   = align_iters_per_s: a3r_align_step on the config-2 graph (N=16, E=84, P=196608), timed in its own
+            region after the forward region (rank-local replica; see DESIGN.md for why it is not sharded).
+  roofline      : the dominant kernel (fp32-MFMA GEMM) -- algorithmic FLOP / HIP-event duration, live.
+  roofline_align: the fused aligner kernel -- algorithmic bytes / HIP-event duration, live.
+  cpu_baseline  : the numpy/C oracle timed on this box's host cores (rank 0, N=1 only), bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+FLOP_PER_PAIR = {(384, 512): 1969.1e9, (288, 512): 1436.1e9, (224, 224): 461.2e9}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="frame pairs per step and per GPU")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--scene-graph", default="swin-3-noncyclic")
+    ap.add_argument("--align-iters", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-align", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from align3r_amd import _lib
+    from align3r_amd.weights import VITL, synthetic_state_dict, hash_uniform
+    from align3r_amd.engine import PairEngine
+    from align3r_amd.aligner import AlignEngine
+    from align3r_amd.dust3r.image_pairs import make_pairs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    H, W, B = a.height, a.width, a.batch
+    P = H * W
+    # ---- synthetic clip: img ~ U(-1,1), pred_depth ~ U(0,1); rank-specific frames
+    frames = []
+    for i in range(a.frames):
+        img = (2.0 * hash_uniform(f"img{i}", 3 * P, 1 + rank)).astype(np.float32).reshape(3, H, W)
+        pd = (hash_uniform(f"pred_depth{i}", P * 3, 1 + rank) + 0.5).astype(np.float32).reshape(H, W, 3)
+        frames.append((torch.from_numpy(img).to(dev), torch.from_numpy(pd).to(dev)))
+    pairs = make_pairs([dict(idx=i) for i in range(a.frames)], a.scene_graph, symmetrize=True)
+    edges = [(p["idx"], q["idx"]) for p, q in pairs]
+    E = len(edges)
+    eng = PairEngine(VITL, synthetic_state_dict(VITL, 0), dev)
+
+    def batch_inputs(step):
+        idx = [edges[(step * B + k) % E] for k in range(B)]
+        return (torch.stack([frames[i][0] for i, _ in idx]), torch.stack([frames[j][0] for _, j in idx]),
+                torch.stack([frames[i][1] for i, _ in idx]), torch.stack([frames[j][1] for _, j in idx]))
+
+    n_batches = min(a.steps + a.warmup, (E + B - 1) // B)
+    inputs = [batch_inputs(s) for s in range(n_batches)]          # resident in HBM before timing
+    flat = torch.empty(B * P * 8, device=dev)                      # one step's outputs, contiguous for the collective
+    out = dict(pts3d_1=flat[:B * P * 3].view(B, H, W, 3), pts3d_2=flat[B * P * 3:B * P * 6].view(B, H, W, 3),
+               conf_1=flat[B * P * 6:B * P * 7].view(B, H, W), conf_2=flat[B * P * 7:].view(B, H, W))
+    gathered = torch.empty(world * B * P * 8, device=dev) if world > 1 else None
+
+    def step(s):
+        eng.forward(*inputs[s % n_batches], out=out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, flat)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        step(s)
+    barrier()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        step(a.warmup + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_report()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pairs_per_s = world * B * a.steps / dt
+    lin = prof[0]
+    achieved = lin["work"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
+    kernels = {p["name"]: dict(launches=p["launches"], total_ms=round(p["ms"], 3),
+                               avg_us=round(1e3 * p["ms"] / p["launches"], 2) if p["launches"] else None,
+                               rate=round(p["work"] / (p["ms"] * 1e-3) / 1e12, 3) if p["ms"] > 0 else None)
+               for p in prof if p["launches"]}
+    flop_pair = FLOP_PER_PAIR.get((H, W))
+    res = {
+        "metric": "frame-pairs/s ViT-L 512px + global-align iters/s, 1/2/4/8 MI355X", "value": round(pairs_per_s, 4),
+        "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.frames}-frame synthetic clip {W}x{H}, ViT-L, {a.scene_graph} symmetrised (E={E}), "
+                               f"{B} pairs/step/GPU, cloud_opt PointCloudOptimizer", "pairs_per_step_per_gpu": B,
+                   "frames": a.frames, "edges": E, "parallelism": f"pair-shard x{world}" + (" + all-gather/step" if world > 1 else "")},
+        "model_tflops_as_reference": round(pairs_per_s * flop_pair / 1e12 / world, 2) if flop_pair else None,
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)", "achieved": round(achieved, 2),
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None, "launches": lin["launches"], "avg_launch_us": round(1e3 * lin["ms"] / max(lin["launches"], 1), 2)},
+        "kernels": kernels,
+    }
+
+    # ---- global alignment (config 2: N=16, E=84, P=H*W), random-init state, its own timed region
+    if not a.no_align:
+        del eng, inputs
+        torch.cuda.empty_cache()
+        g = torch.Generator(device="cpu").manual_seed(2)
+        N = a.frames
+        pi = torch.randn(E, P, 3, generator=g)
+        pj = torch.randn(E, P, 3, generator=g)
+        wi = torch.log(1 + 9 * torch.rand(E, P, generator=g))
+        wj = torch.log(1 + 9 * torch.rand(E, P, generator=g))
+        al = AlignEngine([i for i, j in edges], [j for i, j in edges], pi, pj, wi, wj, [(H, W)] * N, device=dev,
+                         loss_capacity=a.align_iters + 16)
+        al.set_params(pw_poses=torch.randn(E, 8, generator=g), depth=torch.randn(N, P, generator=g) / 10 - 3,
+                      im_poses=torch.randn(N, 7, generator=g), im_focals=torch.full((N,), 20 * float(np.log(max(H, W)))))
+        al.run(5, 0.05, "cosine", total_iters=a.align_iters + 5)
+        barrier()
+        _lib.prof_enable(True)
+        t0 = time.perf_counter()
+        al.run(a.align_iters, 0.05, "cosine", first_iter=5, total_iters=a.align_iters + 5)
+        torch.cuda.synchronize()
+        dta = time.perf_counter() - t0
+        _lib.prof_enable(False)
+        pa = _lib.prof_report()[5]
+        gbs = pa["work"] / (pa["ms"] * 1e-3) / 1e9 if pa["ms"] > 0 else 0.0
+        res["align_iters_per_s"] = round(a.align_iters / dta, 2)
+        res["align_config"] = {"N": N, "E": E, "P": P, "use_mono": False, "iters": a.align_iters}
+        res["roofline_align"] = {"bound": "hbm", "kernel": "align_main_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                 "bytes_per_iter": pa["work"] / max(pa["launches"], 1), "avg_launch_us": round(1e3 * pa["ms"] / max(pa["launches"], 1), 2)}
+        del al
+
+    # ---- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only, bounded sample)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import model_np
+        from oracle.align_ref import AlignOracle, lib as oracle_lib
+        cores = os.cpu_count() or 1
+        sd = synthetic_state_dict(VITL, 0)
+        i0, p0 = (t.cpu().numpy()[None] for t in frames[0])
+        i1, p1 = (t.cpu().numpy()[None] for t in frames[1])
+        t0 = time.perf_counter()
+        model_np.forward(i0, i1, p0, p1, sd, VITL)
+        tc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"1 pair {W}x{H} ViT-L through oracle/model_np.py (numpy + BLAS threads), {tc:.1f} s"}
+        if not a.no_align:
+            rng = np.random.default_rng(2)
+            o = AlignOracle([i for i, j in edges], [j for i, j in edges], rng.standard_normal((E, P, 3), dtype=np.float32),
+                            rng.standard_normal((E, P, 3), dtype=np.float32), np.log(1 + 9 * rng.random((E, P), dtype=np.float32)),
+                            np.log(1 + 9 * rng.random((E, P), dtype=np.float32)), [(H, W)] * a.frames)
+            o.set_params(rng.standard_normal((E, 8)), rng.standard_normal((a.frames, P)) / 10 - 3, rng.standard_normal((a.frames, 7)),
+                         np.full(a.frames, 20 * np.log(max(H, W))))
+            o.run(1, 0.05)
+            t0 = time.perf_counter()
+            o.run(5, 0.05)
+            ta = (time.perf_counter() - t0) / 5
+            res["cpu_baseline"]["align_iters_per_s"] = round(1.0 / ta, 3)
+            res["cpu_baseline"]["align_threads"] = int(oracle_lib().a3r_oracle_num_threads())
+            res["cpu_baseline"]["align_sample"] = f"5 iterations of oracle/align_ref.c (OpenMP) at N={a.frames}, E={E}, P={P}"
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,15 @@ int a3r_version(void);
 /* number of HIP devices visible; does not initialise a context */
 int a3r_device_count(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around every kernel launch of the
+ * library (used by bench.py for the roofline numbers).  a3r_prof_enable(1) clears and starts recording,
+ * a3r_prof_enable(0) stops.  a3r_prof_get synchronises the recorded events and returns, for kernel class
+ * `kernel` (0 <= kernel < a3r_prof_kernel_count()), the number of launches, their summed duration and
+ * the summed algorithmic work (FLOP for the MFMA kernels, bytes for the HBM-bound ones). */
+int a3r_prof_enable(int on);
+int a3r_prof_kernel_count(void);
+int a3r_prof_get(int kernel, const char** name, long* launches, double* total_ms, double* total_work);
+
 /* ------------------------------------------------------------------------------------------------
  * (1) 2-D rotary embedding, in place.  Replaces curope.rope_2d(tokens, positions, base, fwd)
  *     croco/models/curope/curope.cpp:49-69 / kernels.cu:17-108.
