@@ -78,6 +78,13 @@ extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
     a3r_model_s* m = new (std::nothrow) a3r_model_s();
     A3R_CHECK_ARG(m, "out of host memory");
     m->cfg = *cfg;
+    // sized here so that the host-side sizing pass (a3r_model_workspace_bytes) works before finalize
+    m->enc.assign(cfg->enc_depth, BlockW());
+    m->pc.assign(n_pc_blocks(*cfg), BlockW());
+    m->dec1.assign(cfg->dec_depth, BlockW());
+    m->dec2.assign(cfg->dec_depth, BlockW());
+    m->zc_w.assign(n_pc_blocks(*cfg) + 1, nullptr);
+    m->zc_b.assign(n_pc_blocks(*cfg) + 1, nullptr);
     *out = m;
     return A3R_OK;
 }

@@ -1,0 +1,306 @@
+"""PointCloudOptimizer behind the reference's API, computed by liba3r's fused aligner kernels.
+
+Mirrors dust3r/cloud_opt/optimizer.py:16-277 + base_opt.py:45-464 for the stacked fast path: same
+constructor keywords, parameter names / parameterisation (pw_poses [E,8], im_depthmaps | scalemaps+shifts,
+im_poses [N,7], im_focals = focal_break*log f, im_pp), same random initial state for the same torch seed
+(parameters are drawn in the reference's order), same getters and the same optimisation loop
+(Adam betas (0.9, 0.9), cosine/linear schedule).  Gradients are analytic (the reference uses autograd).
+Not available here (raise NotImplementedError): init='mst'/'known_poses' (MST + PnP initialisation, SURVEY
+row N1), allow_pw_adaptors=True, mixed image shapes with different aspect (padding is supported by the
+kernels, see a3r.h, but not wired through this class yet).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ...aligner import AlignEngine
+from .commons import get_conf_trf, get_imshapes, rotmat_to_unitquat, signed_expm1, signed_log1p, unitquat_to_rotmat
+
+
+class PointCloudOptimizer:
+    POSE_DIM = 7
+
+    def __init__(self, view1, view2, pred1, pred2, if_use_mono, mono_depths, dist='l1', conf='log', min_conf_thr=3,
+                 base_scale=0.5, allow_pw_adaptors=False, pw_break=20, rand_pose=torch.randn, iterationsCount=None,
+                 verbose=True, optimize_pp=False, focal_break=20):
+        idx1 = view1['idx'] if isinstance(view1['idx'], list) else torch.as_tensor(view1['idx']).tolist()
+        idx2 = view2['idx'] if isinstance(view2['idx'], list) else torch.as_tensor(view2['idx']).tolist()
+        self.edges = [(int(i), int(j)) for i, j in zip(idx1, idx2)]
+        self.is_symmetrized = set(self.edges) == {(j, i) for i, j in self.edges}
+        if dist not in ('l1', 'l2'):
+            raise KeyError(dist)
+        self.dist = dist
+        self.verbose = verbose
+        self.if_use_mono = bool(if_use_mono)
+        if allow_pw_adaptors:
+            raise NotImplementedError('allow_pw_adaptors=True')
+        indices = sorted({i for e in self.edges for i in e})       # base_opt.py:164-167
+        assert indices == list(range(len(indices))), 'bad pair indices: missing values '
+        self.n_imgs = len(indices)
+        self._pred_i = torch.as_tensor(pred1['pts3d']).float()
+        self._pred_j = torch.as_tensor(pred2['pts3d_in_other_view']).float()
+        self.imshapes = get_imshapes(self.edges, self._pred_i, self._pred_j)
+        self._conf_i = torch.as_tensor(pred1['conf']).float()
+        self._conf_j = torch.as_tensor(pred2['conf']).float()
+        self.min_conf_thr = min_conf_thr
+        self.conf_trf = get_conf_trf(conf)
+        # per-image confidence = max over the edges it appears in (base_opt.py:169-175)
+        im_conf = [torch.zeros(hw) for hw in self.imshapes]
+        for e, (i, j) in enumerate(self.edges):
+            im_conf[i] = torch.maximum(im_conf[i], self._conf_i[e].cpu())
+            im_conf[j] = torch.maximum(im_conf[j], self._conf_j[e].cpu())
+        self.im_conf = im_conf
+        self.base_scale, self.pw_break, self.focal_break = base_scale, pw_break, focal_break
+        self.norm_pw_scale = True
+        self.rand_pose = rand_pose
+        self.has_im_poses = True
+        H, W = self.imshapes[0]
+        if any(s != (H, W) for s in self.imshapes):
+            raise NotImplementedError('images of different shapes in one alignment problem')
+        self.imshape = (H, W)
+        self.max_area = H * W
+        E, N, P = len(self.edges), self.n_imgs, H * W
+        # ---- parameters, drawn in the reference's order (base_opt.py:116; optimizer.py:29-38)
+        init = dict(pw_poses=rand_pose((E, 1 + self.POSE_DIM)))
+        if not self.if_use_mono:
+            init['depth'] = torch.stack([torch.randn(H, W) / 10 - 3 for _ in range(N)]).reshape(N, P)
+            self.mono_depths = None
+        else:
+            init['depth'] = torch.zeros(N, P)
+            init['shifts'] = torch.zeros(N)
+            self.mono_depths = torch.stack([torch.as_tensor(m).float().reshape(P) for m in mono_depths])
+        init['im_poses'] = torch.stack([rand_pose(self.POSE_DIM) for _ in range(N)])
+        init['im_focals'] = torch.full((N,), float(focal_break * np.log(max(H, W))))
+        self._init = init
+        self._flags = dict(train_poses=True, train_focals=True, train_pp=bool(optimize_pp))
+        self.total_area_i = sum(P for _ in self.edges)
+        self.total_area_j = self.total_area_i
+        self.engine = None
+        self.device = torch.device('cpu')
+        self.imgs = None
+        if 'img' in view1 and 'img' in view2:
+            imgs = [None] * N
+            for v in range(E):
+                imgs[self.edges[v][0]] = view1['img'][v]
+                imgs[self.edges[v][1]] = view2['img'][v]
+            self.imgs = [(torch.as_tensor(im).float().cpu().permute(1, 2, 0).numpy() * 0.5 + 0.5).clip(0, 1) for im in imgs]
+
+    # ------------------------------------------------------------------ placement
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('PointCloudOptimizer: this build has no CPU compute path; pass a HIP device ("cuda")')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = device
+        E, P = len(self.edges), self.max_area
+        w_i = self.conf_trf(self._conf_i).reshape(E, P)
+        w_j = self.conf_trf(self._conf_j).reshape(E, P)
+        self.engine = AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i.reshape(E, P, 3),
+                                  self._pred_j.reshape(E, P, 3), w_i, w_j, self.imshapes, mono=self.mono_depths,
+                                  base_scale=self.base_scale, pw_break=self.pw_break, focal_break=self.focal_break,
+                                  norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device, **self._flags)
+        self.engine.set_params(**self._init)
+        self._pred_i = self._pred_j = self._conf_i = self._conf_j = None   # the engine holds the device copies
+        return self
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError('call .to(device) first (global_aligner does)')
+        return self.engine
+
+    @property
+    def n_edges(self):
+        return len(self.edges)
+
+    @property
+    def str_edges(self):
+        return [f'{i}_{j}' for i, j in self.edges]
+
+    @property
+    def imsizes(self):
+        return [(w, h) for h, w in self.imshapes]
+
+    # ------------------------------------------------------------------ parameter views (reference names)
+    @property
+    def pw_poses(self):
+        return self._need_engine().params['pw_poses']
+
+    @property
+    def im_poses(self):
+        return self._need_engine().params['im_poses']
+
+    @property
+    def im_focals(self):
+        return self._need_engine().params['im_focals'][:, None]
+
+    @property
+    def im_pp(self):
+        return self._need_engine().params['im_pp']
+
+    @property
+    def im_depthmaps(self):
+        assert not self.if_use_mono
+        return self._need_engine().params['depth']
+
+    @property
+    def scalemaps(self):
+        assert self.if_use_mono
+        return self._need_engine().params['depth']
+
+    @property
+    def shifts(self):
+        assert self.if_use_mono
+        return self._need_engine().params['shifts'][:, None]
+
+    # ------------------------------------------------------------------ getters (optimizer.py:137-206, base_opt.py:184-229)
+    def _get_poses(self, poses):
+        Q = poses[:, :4]
+        Q = Q / Q.norm(dim=-1, keepdim=True)
+        T = signed_expm1(poses[:, 4:7])
+        RT = torch.zeros(poses.shape[0], 4, 4, device=poses.device)
+        RT[:, :3, :3] = unitquat_to_rotmat(Q)
+        RT[:, :3, 3] = T
+        RT[:, 3, 3] = 1
+        return RT
+
+    def get_pw_norm_scale_factor(self):
+        if self.norm_pw_scale:
+            return (np.log(self.base_scale) - self.pw_poses[:, -1].mean()).exp()
+        return 1
+
+    def get_pw_scale(self):
+        return self.pw_poses[:, -1].exp() * self.get_pw_norm_scale_factor()
+
+    def get_pw_poses(self):
+        RT = self._get_poses(self.pw_poses)
+        RT[:, :3] *= self.get_pw_scale().view(-1, 1, 1)
+        return RT
+
+    def get_im_poses(self):
+        return self._get_poses(self.im_poses)
+
+    def get_focals(self):
+        return (self.im_focals / self.focal_break).exp()
+
+    def get_principal_points(self):
+        return self._need_engine().pp0 + 10 * self.im_pp
+
+    def get_intrinsics(self):
+        K = torch.zeros((self.n_imgs, 3, 3), device=self.device)
+        f = self.get_focals().flatten()
+        K[:, 0, 0] = K[:, 1, 1] = f
+        K[:, :2, 2] = self.get_principal_points()
+        K[:, 2, 2] = 1
+        return K
+
+    def get_known_focal_mask(self):
+        return torch.tensor([not self._flags['train_focals']] * self.n_imgs)
+
+    def get_depthmaps(self, raw=False):
+        p = self._need_engine().params
+        if not self.if_use_mono:
+            res = p['depth'].exp()
+        else:
+            res = self.engine.mono * p['depth'].exp() + p['shifts'][:, None]
+        if not raw:
+            res = [dm[:h * w].view(h, w) for dm, (h, w) in zip(res, self.imshapes)]
+        return res
+
+    def depth_to_pts3d(self):
+        H, W = self.imshape
+        depth = self.get_depthmaps(raw=True)                                   # [N,P]
+        ys, xs = torch.meshgrid(torch.arange(H, device=self.device), torch.arange(W, device=self.device), indexing='ij')
+        grid = torch.stack((xs, ys), -1).reshape(1, H * W, 2).float()
+        pp = self.get_principal_points()[:, None]
+        f = self.get_focals()[:, None]
+        rel = torch.cat((depth[..., None] * (grid - pp) / f, depth[..., None]), -1)
+        RT = self.get_im_poses()
+        return torch.einsum('bij,bpj->bpi', RT[:, :3, :3], rel) + RT[:, None, :3, 3]
+
+    def get_pts3d(self, raw=False):
+        res = self.depth_to_pts3d()
+        if not raw:
+            res = [dm[:h * w].view(h, w, 3) for dm, (h, w) in zip(res, self.imshapes)]
+        return res
+
+    def get_conf(self, mode=None):
+        trf = self.conf_trf if mode is None else get_conf_trf(mode)
+        return [trf(c) for c in self.im_conf]
+
+    def get_masks(self):
+        return [(conf > self.min_conf_thr) for conf in self.im_conf]
+
+    # ------------------------------------------------------------------ presets (optimizer.py:76-113)
+    def _msk_indices(self, msk):
+        if msk is None:
+            return list(range(self.n_imgs))
+        if isinstance(msk, int):
+            return [msk]
+        msk = np.asarray(msk)
+        return np.where(msk)[0].tolist() if msk.dtype == bool else msk.tolist()
+
+    def _check_all(self, msk):
+        assert self._msk_indices(msk) == list(range(self.n_imgs)), 'incomplete mask!'
+
+    def preset_pose(self, known_poses, pose_msk=None):
+        self._check_all(pose_msk)
+        if isinstance(known_poses, torch.Tensor) and known_poses.ndim == 2:
+            known_poses = [known_poses]
+        poses = self.im_poses.clone()
+        for idx, pose in zip(self._msk_indices(pose_msk), known_poses):
+            pose = torch.as_tensor(pose, dtype=torch.float32).cpu()
+            poses[idx, 0:4] = rotmat_to_unitquat(pose[:3, :3]).to(poses.device)
+            poses[idx, 4:7] = signed_log1p(pose[:3, 3]).to(poses.device)
+        self.norm_pw_scale = False
+        self._flags['train_poses'] = False
+        e = self._need_engine()
+        e.flags.update(norm_pw_scale=False, train_poses=False)
+        e.set_params(im_poses=poses)
+
+    def preset_focal(self, known_focals, msk=None):
+        self._check_all(msk)
+        f = self._need_engine().params['im_focals'].clone()
+        for idx, focal in zip(self._msk_indices(msk), known_focals):
+            f[idx] = self.focal_break * float(np.log(float(focal)))
+        self._flags['train_focals'] = False
+        self.engine.flags.update(train_focals=False)
+        self.engine.set_params(im_focals=f)
+
+    def preset_principal_point(self, known_pp, msk=None):
+        self._check_all(msk)
+        pp = self.im_pp.clone()
+        H, W = self.imshape
+        for idx, p in zip(self._msk_indices(msk), known_pp):
+            pp[idx] = (torch.as_tensor(p, dtype=torch.float32).to(pp.device) - torch.tensor([W / 2, H / 2], device=pp.device)) / 10
+        self._flags['train_pp'] = False
+        self.engine.flags.update(train_pp=False)
+        self.engine.set_params(im_pp=pp)
+
+    # ------------------------------------------------------------------ optimisation (base_opt.py:373-464)
+    def forward(self):
+        """The alignment loss of the current state (a 0-d device tensor)."""
+        return self._need_engine().loss()[0]
+
+    __call__ = forward
+
+    def compute_global_alignment(self, init=None, init_priors=None, niter_PnP=10, lr=0.01, niter=300, schedule='cosine',
+                                 lr_min=1e-6):
+        if init is not None:
+            if init in ('msp', 'mst', 'known_poses'):
+                raise NotImplementedError(f"init={init!r}: the MST / PnP initialisation (init_im_poses.py) is SURVEY row N1 "
+                                          "('next'); start from init=None or set the state with set_params()")
+            raise ValueError(f'bad value for {init=}')
+        e = self._need_engine()
+        if schedule not in ('cosine', 'linear'):
+            raise ValueError(f'bad lr {schedule=}')
+        if niter <= 0:
+            return float('inf')
+        if e.steps_done + niter > e.loss_capacity:
+            raise RuntimeError('loss history capacity exceeded')
+        e.set_params(reset_optimizer=True)            # a fresh torch.optim.Adam per call (base_opt.py:435)
+        losses = e.run(niter, lr, schedule, lr_min)
+        if self.verbose:
+            print(f'Global alignement - {niter} iterations, final lr={lr_min if niter > 1 else lr:g} loss={losses[-1]:g}')
+        return float(losses[-1])

@@ -1,0 +1,59 @@
+"""Pair inference loop with the reference's interface (dust3r/inference.py:32-78).
+
+``inference(pairs, model, device, batch_size=8, verbose=True)`` returns the same nested dict
+{view1, view2, pred1, pred2, loss}; like the reference, everything is moved to the CPU after each batch
+unless ``keep_on_device=True`` (an extension used by the multi-GPU path to hand device tensors straight
+to the aligner).  All reference drivers call it with batch_size=1; larger batches amortise weight reads.
+"""
+from __future__ import annotations
+
+import torch
+
+from .utils.device import collate_with_cat, to_cpu
+
+_IGNORE_KEYS = {'depthmap', 'dataset', 'label', 'instance', 'idx', 'true_shape', 'rng'}
+
+
+def loss_of_one_batch(batch, model, criterion, device, symmetrize_batch=False, use_amp=False, ret=None):
+    view1, view2 = batch
+    for view in batch:
+        for name in view.keys():
+            if name in _IGNORE_KEYS:
+                continue
+            view[name] = view[name].to(device, non_blocking=True)
+    if symmetrize_batch:
+        raise NotImplementedError('symmetrize_batch is a training-time option')
+    if use_amp:
+        raise NotImplementedError('use_amp: the engine computes in fp32')
+    pred1, pred2 = model(view1, view2)
+    loss = criterion(view1, view2, pred1, pred2) if criterion is not None else None
+    result = dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=loss)
+    return result[ret] if ret else result
+
+
+def check_if_same_size(pairs):
+    shapes1 = [img1['img'].shape[-2:] for img1, img2 in pairs]
+    shapes2 = [img2['img'].shape[-2:] for img1, img2 in pairs]
+    return all(shapes1[0] == s for s in shapes1) and all(shapes2[0] == s for s in shapes2)
+
+
+@torch.no_grad()
+def inference(pairs, model, device, batch_size=8, verbose=True, keep_on_device=False):
+    if verbose:
+        print(f'>> Inference with model on {len(pairs)} image pairs')
+    result = []
+    multiple_shapes = not check_if_same_size(pairs)
+    if multiple_shapes:
+        batch_size = 1
+    rng = range(0, len(pairs), batch_size)
+    if verbose:
+        try:
+            import tqdm
+            rng = tqdm.trange(0, len(pairs), batch_size)
+        except ImportError:
+            pass
+    for i in rng:
+        # shallow-copy the view dicts: collate builds new dicts, the caller's views are not modified
+        res = loss_of_one_batch(collate_with_cat(pairs[i:i + batch_size]), model, None, device)
+        result.append(res if keep_on_device else to_cpu(res))
+    return collate_with_cat(result, lists=multiple_shapes)

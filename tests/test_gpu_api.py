@@ -1,0 +1,109 @@
+"""GPU: the drop-in flow a reference driver runs (tool/depth_test.py:628-650 shape of calls), through the mirror
+API: checkpoint -> from_pretrained -> make_pairs -> inference -> global_aligner -> compute_global_alignment."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, make_view_arrays, rel_err
+from align3r_amd.weights import TINY, model_string, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(n, H, W, seed=1):
+    out = []
+    for i, (img, pd) in enumerate(make_view_arrays(n, H, W, seed)):
+        out.append(dict(img=torch.from_numpy(img), pred_depth=torch.from_numpy(pd), true_shape=np.int32([[H, W]]), idx=i,
+                        instance=str(i)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    import align3r_amd
+    align3r_amd.install_as_dust3r()
+    from dust3r.model import AsymmetricCroCo3DStereo, _parse_model_string, save_checkpoint
+    kw = _parse_model_string(model_string(TINY))
+    m = AsymmetricCroCo3DStereo(**{**kw, "landscape_only": False})
+    path = str(tmp_path_factory.mktemp("ckpt") / "tiny.pth")
+    save_checkpoint(path, m)
+    return AsymmetricCroCo3DStereo.from_pretrained(path).to("cuda")
+
+
+def test_inference_api_vs_reference_golden(model):
+    from dust3r.image_pairs import make_pairs
+    from dust3r.inference import inference
+    t = np.load(os.path.join(GOLDEN, "tiny_e2e.npz"))
+    pairs = make_pairs(_views(2, 64, 96), scene_graph="complete", prefilter=None, symmetrize=True)
+    assert [(a["idx"], b["idx"]) for a, b in pairs] == [(1, 0), (0, 1)]
+    for bs in (1, 8):
+        out = inference(pairs, model, "cuda", batch_size=bs, verbose=False)
+        assert out["pred1"]["pts3d"].device.type == "cpu" and out["loss"] is None       # to_cpu after every batch
+        # pred_mask is the python int 0 per BATCH in the reference (dpt_head.py:65) -> one entry per batch after collation
+        assert out["view1"]["idx"] == [1, 0] and out["pred1"]["pred_mask"] == [0] * (2 if bs == 1 else 1)
+        assert rel_err(out["pred1"]["pts3d"].numpy(), t["a_pts3d_1"]) < 1e-4
+        assert rel_err(out["pred1"]["conf"].numpy(), t["a_conf_1"]) < 1e-4
+        assert rel_err(out["pred2"]["pts3d_in_other_view"].numpy(), t["a_pts3d_2"]) < 1e-4
+        assert rel_err(out["pred2"]["conf"].numpy(), t["a_conf_2"]) < 1e-4
+
+
+@pytest.mark.parametrize("use_mono", [False, True])
+def test_alignment_api_vs_oracle_chain(model, use_mono):
+    from dust3r.image_pairs import make_pairs
+    from dust3r.inference import inference
+    from dust3r.cloud_opt import global_aligner, GlobalAlignerMode
+    from oracle.align_ref import AlignOracle
+    H, W, n = 48, 64, 4
+    views = _views(n, H, W, seed=3)
+    pairs = make_pairs(views, scene_graph="swin-2-noncyclic", symmetrize=True)
+    out = inference(pairs, model, "cuda", batch_size=4, verbose=False)
+    out["pred1"]["conf"][out["pred1"]["conf"] > 10] = 10          # tool/depth_test.py:638-639 style clamp
+    mono = [torch.from_numpy(0.5 + v["pred_depth"][0, :, :, 0].numpy()) for v in views] if use_mono else []
+    torch.manual_seed(5)
+    scene = global_aligner(out, use_mono, mono, "cuda", mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False, min_conf_thr=3)
+    init = {k: v.clone() for k, v in scene._init.items()}
+    loss0 = float(scene())
+    loss = scene.compute_global_alignment(init=None, niter=30, schedule="cosine", lr=0.05)
+    assert loss < loss0
+    # same problem through the C oracle
+    edges = scene.edges
+    E, P = len(edges), H * W
+    o = AlignOracle([i for i, j in edges], [j for i, j in edges], out["pred1"]["pts3d"].numpy().reshape(E, P, 3),
+                    out["pred2"]["pts3d_in_other_view"].numpy().reshape(E, P, 3), np.log(out["pred1"]["conf"].numpy()).reshape(E, P),
+                    np.log(out["pred2"]["conf"].numpy()).reshape(E, P), [(H, W)] * n,
+                    mono=np.stack([m.numpy() for m in mono]) if use_mono else None)
+    o.set_params(init["pw_poses"].numpy(), init["depth"].numpy(), init["im_poses"].numpy(), init["im_focals"].numpy(),
+                 shifts=init["shifts"].numpy() if use_mono else None)
+    lo = o.run(30, 0.05, "cosine")
+    assert abs(loss - lo[-1]) / lo[-1] < 1e-4
+    depth = torch.stack(scene.get_depthmaps()).cpu().numpy().reshape(n, P)
+    d_ref = (o.mono * np.exp(o.params["depth"]) + o.params["shifts"][:, None]) if use_mono else np.exp(o.params["depth"])
+    assert rel_err(depth, d_ref) < 1e-4                            # aligned depths within 1e-4 relative
+    eM, iR, f, pp = o.pose_matrices()
+    assert rel_err(scene.get_im_poses()[:, :3].cpu().numpy(), iR) < 1e-4
+    assert rel_err(scene.get_focals().cpu().numpy().ravel(), f) < 1e-4
+    assert rel_err(scene.get_pw_poses()[:, :3].cpu().numpy(), eM) < 1e-4
+    assert scene.get_pts3d()[0].shape == (H, W, 3) and scene.get_intrinsics().shape == (n, 3, 3)
+    assert len(scene.get_masks()) == n and scene.get_conf()[0].shape == (H, W)
+    with pytest.raises(NotImplementedError, match="N1"):
+        scene.compute_global_alignment(init="mst", niter=1)
+
+
+def test_preset_pose_freezes_poses(model):
+    from dust3r.cloud_opt import global_aligner
+    H, W = 32, 32
+    E = 2
+    g = torch.Generator().manual_seed(0)
+    out = dict(view1=dict(idx=[0, 1]), view2=dict(idx=[1, 0]),
+               pred1=dict(pts3d=torch.randn(E, H, W, 3, generator=g), conf=1 + torch.rand(E, H, W, generator=g)),
+               pred2=dict(pts3d_in_other_view=torch.randn(E, H, W, 3, generator=g), conf=1 + torch.rand(E, H, W, generator=g)))
+    scene = global_aligner(out, False, [], "cuda", verbose=False)
+    poses = [torch.eye(4), torch.tensor([[0., -1, 0, 1], [1, 0, 0, 2], [0, 0, 1, 3], [0, 0, 0, 1]])]
+    scene.preset_pose(poses)
+    scene.preset_focal([300.0, 310.0])
+    got = scene.get_im_poses().cpu()
+    assert rel_err(got[1].numpy(), poses[1].numpy()) < 1e-6
+    scene.compute_global_alignment(init=None, niter=5, lr=0.05)
+    assert torch.allclose(scene.get_im_poses().cpu(), got) and rel_err(scene.get_focals().cpu().numpy().ravel(), [300.0, 310.0]) < 1e-5

@@ -1,0 +1,108 @@
+"""CPU: host-side mirror of the reference API -- checkpoint format, state-dict rules, the aligner's random
+initial state (pinned to the reference's for the same torch seed), collation helpers."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from align3r_amd.weights import TINY, VITL, model_string, param_spec, synthetic_state_dict
+from align3r_amd.dust3r.model import AsymmetricCroCo3DStereo, _parse_model_string, load_model, save_checkpoint
+from align3r_amd.dust3r.utils.device import collate_with_cat, to_cpu, to_numpy
+
+inf = float("inf")
+
+
+def tiny_kwargs():
+    kw = _parse_model_string(model_string(TINY))
+    kw["landscape_only"] = False
+    return kw
+
+
+def test_param_inventory_matches_reference_count():
+    n = sum(int(np.prod(s)) for _, s, _ in param_spec(VITL))
+    assert n == 603_070_000 + 0 or abs(n - 603.07e6) < 0.01e6        # 603.07 M parameters
+
+
+def test_model_string_and_constructor_checks():
+    kw = _parse_model_string(model_string(VITL))
+    assert kw["enc_embed_dim"] == 1024 and kw["depth_mode"] == ("exp", -inf, inf) and kw["img_size"] == (512, 512)
+    with pytest.raises(ValueError):
+        _parse_model_string("__import__('os').system('true')")
+    with pytest.raises(NotImplementedError):
+        AsymmetricCroCo3DStereo(head_type="linear", pos_embed="RoPE100")
+    with pytest.raises(AssertionError, match="must be multiple of"):
+        AsymmetricCroCo3DStereo(head_type="dpt", pos_embed="RoPE100", img_size=(500, 512))
+
+
+def test_state_dict_rules_and_checkpoint_roundtrip(tmp_path):
+    m = AsymmetricCroCo3DStereo(**tiny_kwargs())
+    sd = m.state_dict()
+    assert "downstream_head1.dpt.scratch.layer_rn.0.weight" in sd            # duplicated key of the reference
+    # a DUSt3R-style checkpoint without dec_blocks2: duplicated from dec_blocks (model.py:114-121)
+    partial = {k: v for k, v in sd.items() if not k.startswith("dec_blocks2")}
+    m2 = AsymmetricCroCo3DStereo(**tiny_kwargs())
+    r = m2.load_state_dict(partial, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    assert torch.equal(m2.state_dict()["dec_blocks2.3.attn.qkv.weight"], sd["dec_blocks.3.attn.qkv.weight"])
+    assert torch.equal(m2.state_dict()["dec_blocks_pc.0.attn.qkv.weight"], sd["dec_blocks_pc.0.attn.qkv.weight"])
+    with pytest.raises(RuntimeError, match="Missing key"):
+        AsymmetricCroCo3DStereo(**tiny_kwargs()).load_state_dict({k: v for k, v in sd.items() if "enc_norm" not in k})
+    bad = dict(sd)
+    bad["enc_norm.weight"] = torch.zeros(7)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        AsymmetricCroCo3DStereo(**tiny_kwargs()).load_state_dict(bad)
+    path = str(tmp_path / "ckpt.pth")
+    save_checkpoint(path, m)
+    m3 = AsymmetricCroCo3DStereo.from_pretrained(path)            # load_model: PatchEmbedDust3R, landscape_only=False
+    assert m3.patch_embed_cls == "PatchEmbedDust3R" and m3.landscape_only is False
+    for k, v in m3.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    with pytest.raises(Exception, match="huggingface"):
+        AsymmetricCroCo3DStereo.from_pretrained("some/hub-name")
+    with pytest.raises(RuntimeError, match="no CPU compute path"):
+        m3.forward(dict(img=torch.zeros(1, 3, 32, 32), pred_depth=torch.zeros(1, 32, 32, 3)),
+                   dict(img=torch.zeros(1, 3, 32, 32), pred_depth=torch.zeros(1, 32, 32, 3)))
+
+
+def test_collate_and_device_helpers():
+    a = dict(img=torch.ones(1, 3, 4, 4), idx=0, instance="0", true_shape=np.int32([[4, 4]]))
+    b = dict(img=torch.zeros(1, 3, 4, 4), idx=1, instance="1", true_shape=np.int32([[4, 4]]))
+    v1, v2 = collate_with_cat([(a, b), (b, a)])
+    assert v1["img"].shape == (2, 3, 4, 4) and v1["idx"] == [0, 1] and v2["instance"] == ["1", "0"]
+    assert v1["true_shape"].shape == (2, 2) and v1["true_shape"].dtype == torch.int32
+    assert collate_with_cat([dict(loss=None), dict(loss=None)])["loss"] is None
+    n = to_numpy(dict(x=[torch.ones(2)], y=(torch.zeros(1),)))
+    assert isinstance(n["x"][0], np.ndarray) and isinstance(n["y"], tuple)
+    assert to_cpu(dict(k=torch.ones(1)))["k"].device.type == "cpu"
+
+
+def test_aligner_initial_state_matches_reference_for_same_seed():
+    """The reference draws pw_poses, then per-image log-depth maps, then per-image poses from torch's global RNG
+    (base_opt.py:116, optimizer.py:29-35).  Same seed => same initial parameters as captured in the goldens."""
+    from align3r_amd.dust3r.cloud_opt.optimizer import PointCloudOptimizer
+    g = np.load(os.path.join(GOLDEN, "align.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "align.json")))
+    for case in meta["cases"]:
+        if case["use_mono"]:
+            continue
+        tag, edges, H, W = case["tag"], case["edges"], case["H"], case["W"]
+        view1 = dict(idx=[i for i, j in edges])
+        view2 = dict(idx=[j for i, j in edges])
+        pred1 = dict(pts3d=torch.from_numpy(g[tag + "_p1"]), conf=torch.from_numpy(g[tag + "_c1"]))
+        pred2 = dict(pts3d_in_other_view=torch.from_numpy(g[tag + "_p2"]), conf=torch.from_numpy(g[tag + "_c2"]))
+        torch.manual_seed(11)
+        net = PointCloudOptimizer(view1, view2, pred1, pred2, False, [], verbose=False, min_conf_thr=3)
+        assert np.array_equal(net._init["pw_poses"].numpy(), g[tag + "_init_pw_poses"])
+        assert np.array_equal(net._init["depth"].numpy().reshape(g[tag + "_init_im_depthmaps"].shape), g[tag + "_init_im_depthmaps"])
+        assert np.array_equal(net._init["im_poses"].numpy(), g[tag + "_init_im_poses"])
+        assert np.array_equal(net._init["im_focals"].numpy().reshape(-1, 1), g[tag + "_init_im_focals"])
+        assert net.is_symmetrized and net.n_imgs == case["N"]
+        with pytest.raises(RuntimeError, match="no CPU compute path"):
+            net.to("cpu")
+    bad = dict(idx=[0, 2])
+    with pytest.raises(AssertionError, match="bad pair indices"):
+        PointCloudOptimizer(bad, dict(idx=[2, 0]), dict(pts3d=torch.zeros(2, 4, 4, 3), conf=torch.ones(2, 4, 4)),
+                            dict(pts3d_in_other_view=torch.zeros(2, 4, 4, 3), conf=torch.ones(2, 4, 4)), False, [])
