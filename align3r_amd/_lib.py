@@ -22,6 +22,10 @@ class Epilogue(C.Structure):
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int)]
 
 
+class GroupPtrs(C.Structure):
+    _fields_ = [("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("resid", c_void), ("resid2", c_void)]
+
+
 class ModelConfigC(C.Structure):
     _fields_ = [("enc_embed_dim", C.c_int), ("enc_depth", C.c_int), ("enc_num_heads", C.c_int),
                 ("dec_embed_dim", C.c_int), ("dec_depth", C.c_int), ("dec_num_heads", C.c_int),
@@ -56,6 +60,7 @@ SIGNATURES = {
     "a3r_rope2d": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_void]),
     "a3r_layernorm": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
     "a3r_linear": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
+    "a3r_linear_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_conv3x3": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_pack_conv3x3": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void]),
     "a3r_pack_convT": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void]),

@@ -8,43 +8,64 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32 products and fp32 accumulation (a k-ordered fmaf
 // chain), so results differ from the reference's fp32 CPU path only by summation order.
 //
-// Tiling (64-wide waves): workgroup = 4 waves = 128x128 output tile, each wave a 64x64 sub-tile held as
-// 2x2 MFMA accumulators (64 VGPRs); K is walked in 32-deep slabs staged global -> registers -> LDS
-// (double-buffered, rows padded 32 -> 36 floats so ds_read_b128 of 16 different rows is conflict-free).
-// Inside a slab the k index is permuted so that one ds_read_b128 feeds four consecutive MFMAs:
-// lane half h of MFMA step t consumes k = 8*kb + 4*h + t for both operands (sums commute).
-// Workgroup ids are remapped so that the 8 XCDs each walk a contiguous run of tiles (private L2s).
+// Tiling (64-wide waves): a workgroup is 4 waves (2x2) over a BM x BN output tile, BM x BN in
+// {128x128, 128x64, 64x64}; each wave holds (BM/64) x (BN/64) MFMA accumulators of 32x32.  The launcher
+// picks the tile so that the grid fills the 256 CUs (the ViT-L problems are 144..1536 tiles of 128x128:
+// tail quantisation, not the main loop, is what costs throughput -- see tools/gemm_lab.hip).
+// K is walked in 32-deep slabs staged global -> registers -> LDS (double-buffered, rows padded 32 -> 36
+// floats so ds_read_b128 of 16 different rows is conflict-free).  Inside a slab the k index is permuted so
+// that one ds_read_b128 feeds four consecutive MFMAs: lane half h of MFMA step t consumes
+// k = 8*kb + 4*h + t for both operands (sums commute).  Workgroup ids are remapped so that the 8 XCDs
+// each walk a contiguous run of tiles (private L2s).  Up to 4 same-shape problems (different operands:
+// the two decoders) can share one launch ("grouped").
 #include "common.h"
+#include <cstdlib>
 
 namespace a3r {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDP = 36;
-constexpr int GEMM_LDS_BYTES = 2 * (BM + BN) * LDP * 4;   // 73,728 B
+constexpr int BK = 32, LDP = 36;
+
+struct GroupPtrs {
+    const float* A;
+    const float* Wt;        // [N, K]
+    float* C;
+    const float* bias;
+    const float* resid;
+    const float* resid2;
+};
 
 struct GemmArgs {
-    const float* A; int lda;
-    const float* Wt;        // [N, K]
-    float* C; int ldc;
+    GroupPtrs grp[4];
+    int groups, tiles_per_group;
+    int lda, ldc;
     int M, N, K;
     int tiles_m, tiles_n;
-    a3r_epilogue epi;
+    a3r_epilogue epi;       // pointers inside are ignored (taken from grp[]) except the rope tables
     // implicit conv (AMODE 1): A = x [B, H, W, Cin]
     int cH, cW, cCin, cHo, cWo, cStride;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int AMODE>
+// AMODE 0: A is [M, lda] row-major.  AMODE 1: implicit 3x3 conv gather.
+// FULL: M % BM == 0 && N % BN == 0 (no bounds predication; AMODE 0 only).  RELU_A: relu on the A operand.
+template <int AMODE, int BM, int BN, bool FULL, bool RELU_A>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+    constexpr int TM = BM / 64, TN = BN / 64;        // MFMA tiles per wave (waves are 2 x 2)
+    constexpr int WTM = BM / 2, WTN = BN / 2;        // wave tile
+    constexpr int RA = BM / 32, RB = BN / 32;        // float4 per thread per slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);                 // [2][BM][LDP]
     float* Bs = As + 2 * BM * LDP;                              // [2][BN][LDP]
 
     // XCD-aware bijective remap (blocks b and b+8 share an XCD)
-    const int nwg = g.tiles_m * g.tiles_n;
+    const int nwg = g.tiles_per_group * g.groups;
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int grp = wgid / g.tiles_per_group;
+    wgid -= grp * g.tiles_per_group;
+    const GroupPtrs& P = g.grp[grp];
     const int tile_m = wgid / g.tiles_n, tile_n = wgid - tile_m * g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -52,19 +73,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
 
-    // per-thread row bookkeeping for the 4 A rows and 4 B rows it stages
-    const float* a_ptr[4];
-    bool a_ok[4];
-    int a_oy[4], a_ox[4];
-    const float* b_ptr[4];
-    bool b_ok[4];
+    const float* a_ptr[RA];
+    bool a_ok[RA];
+    int a_oy[RA], a_ox[RA];
+    const float* b_ptr[RB];
+    bool b_ok[RB];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = lrow + 32 * i;
-        const int gm = m0 + row;
-        a_ok[i] = gm < g.M;
+    for (int i = 0; i < RA; i++) {
+        const int gm = m0 + lrow + 32 * i;
+        a_ok[i] = FULL || gm < g.M;
         if (AMODE == 0) {
-            a_ptr[i] = g.A + (size_t)(a_ok[i] ? gm : 0) * g.lda + lc4;
+            a_ptr[i] = P.A + (size_t)(a_ok[i] ? gm : 0) * g.lda + lc4;
             a_oy[i] = a_ox[i] = 0;
         } else {
             const int mm = a_ok[i] ? gm : 0;
@@ -73,14 +92,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             const int oy = rem / g.cWo, ox = rem - oy * g.cWo;
             a_oy[i] = oy * g.cStride - 1;
             a_ox[i] = ox * g.cStride - 1;
-            a_ptr[i] = g.A + (size_t)b * g.cH * g.cW * g.cCin + lc4;
+            a_ptr[i] = P.A + (size_t)b * g.cH * g.cW * g.cCin + lc4;
         }
-        const int gn = n0 + row;
-        b_ok[i] = gn < g.N;
-        b_ptr[i] = g.Wt + (size_t)(b_ok[i] ? gn : 0) * g.K + lc4;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const int gn = n0 + lrow + 32 * i;
+        b_ok[i] = FULL || gn < g.N;
+        b_ptr[i] = P.Wt + (size_t)(b_ok[i] ? gn : 0) * g.K + lc4;
     }
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[RA], rb[RB];
     auto load_tile = [&](int k0) {
         int dy = 0, dx = 0, ci0 = 0;
         if (AMODE == 1) {
@@ -89,36 +111,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             dy = tap / 3; dx = tap - dy * 3;
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < RA; i++) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (AMODE == 0) {
-                if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
+                if (FULL || a_ok[i]) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
             } else {
                 const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
                 if (a_ok[i] && iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
                     v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((size_t)iy * g.cW + ix) * g.cCin + ci0);
             }
-            if (g.epi.relu_a) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[i]) w = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
+            if (FULL || b_ok[i]) w = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
             rb[i] = w;
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = lrow + 32 * i;
-            *reinterpret_cast<f32x4*>(As + (buf * BM + row) * LDP + lc4) = ra[i];
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + row) * LDP + lc4) = rb[i];
+        for (int i = 0; i < RA; i++) {
+            f32x4 v = ra[i];
+            if (RELU_A) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + 32 * i) * LDP + lc4) = v;
         }
+#pragma unroll
+        for (int i = 0; i < RB; i++) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + 32 * i) * LDP + lc4) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
@@ -130,21 +156,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const float* Ab = As + (buf * BM + wm * 64 + frow) * LDP + fk;
-        const float* Bb = Bs + (buf * BN + wn * 64 + frow) * LDP + fk;
+        const float* Ab = As + (buf * BM + wm * WTM + frow) * LDP + fk;
+        const float* Bb = Bs + (buf * BN + wn * WTN + frow) * LDP + fk;
 #pragma unroll
         for (int kb = 0; kb < BK / 8; kb++) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + kb * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + 32 * LDP + kb * 8);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bb + kb * 8);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bb + 32 * LDP + kb * 8);
+            f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDP + kb * 8);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDP + kb * 8);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
@@ -153,47 +180,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     // ---------------------------------------------------------------- epilogue
     const a3r_epilogue& ep = g.epi;
     const int half = lane >> 5, lcol = lane & 31;
+    const int epi = ep.epi;
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        const int col = n0 + wn * 64 + nt * 32 + lcol;
-        const bool col_ok = col < g.N;
-        const float bias = (ep.bias && col_ok) ? ep.bias[ep.epi == A3R_EPI_PIXSHUF ? col % ep.ps_cout : col] : 0.f;
-        const bool do_rope = ep.epi == A3R_EPI_ROPE && (n0 + wn * 64) < ep.rope_cols;   // wave-uniform
+    for (int j = 0; j < TN; j++) {
+        const int colbase = n0 + wn * WTN + j * 32;
+        const int col = colbase + lcol;
+        const bool col_ok = FULL || col < g.N;
+        const float bias = (P.bias && col_ok) ? P.bias[epi == A3R_EPI_PIXSHUF ? col % ep.ps_cout : col] : 0.f;
+        const bool do_rope = epi == A3R_EPI_ROPE && colbase < ep.rope_cols;   // wave-uniform (rope_cols % 64 == 0)
+        const bool rope_x = (colbase & 32) != 0;                               // second half of the head rotates with x
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
+        for (int i = 0; i < TM; i++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int row = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                float v = acc[mt][nt][e] + bias;
+                const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                float v = acc[i][j][e] + bias;
                 if (do_rope) {
-                    // pairs (d, d+16) inside each 32-wide half of the head; nt = 0 -> y position, 1 -> x
+                    // pairs (d, d+16) inside each 32-wide half of the head (RoPE2D pos_embed.py:130-157)
                     const float other = __shfl_xor(v, 16);
                     const int tok = row % ep.tokens_per_image;
                     const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
-                    const int p = nt == 0 ? py : px;
+                    const int p = rope_x ? px : py;
                     const float c = ep.rope_cos[p * 16 + (lcol & 15)], s = ep.rope_sin[p * 16 + (lcol & 15)];
                     v = (lcol & 16) ? v * c + other * s : v * c - other * s;
                 }
-                if (row < g.M && col_ok) {
-                    switch (ep.epi) {
-                        case A3R_EPI_GELU: v = gelu_erf(v); break;
-                        case A3R_EPI_RELU: v = fmaxf(v, 0.f); break;
-                        case A3R_EPI_RESID: v = ep.resid[(size_t)row * g.ldc + col] + v; break;
-                        case A3R_EPI_RESID2:
-                            v = ep.resid[(size_t)row * g.ldc + col] + ep.resid2[(size_t)row * g.ldc + col] + v;
-                            break;
-                        default: break;
-                    }
-                    if (ep.epi == A3R_EPI_PIXSHUF) {
+                if ((FULL || row < g.M) && col_ok) {
+                    if (epi == A3R_EPI_GELU) v = gelu_erf(v);
+                    else if (epi == A3R_EPI_RELU) v = fmaxf(v, 0.f);
+                    else if (epi == A3R_EPI_RESID) v = P.resid[(size_t)row * g.ldc + col] + v;
+                    else if (epi == A3R_EPI_RESID2) v = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v;
+                    if (epi == A3R_EPI_PIXSHUF) {
                         const int s = ep.ps_s, hw = ep.ps_h * ep.ps_w;
                         const int b = row / hw, rem = row - b * hw;
                         const int y = rem / ep.ps_w, x = rem - y * ep.ps_w;
                         const int tap = col / ep.ps_cout, co = col - tap * ep.ps_cout;
                         const int dy = tap / s, dx = tap - dy * s;
                         const size_t opix = ((size_t)b * ep.ps_h * s + (y * s + dy)) * (ep.ps_w * s) + (x * s + dx);
-                        g.C[opix * ep.ps_cout + co] = v;
+                        P.C[opix * ep.ps_cout + co] = v;
                     } else {
-                        g.C[(size_t)row * g.ldc + col] = v;
+                        P.C[(size_t)row * g.ldc + col] = v;
                     }
                 }
             }
@@ -201,36 +226,61 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
-static int launch_gemm(int amode, GemmArgs& g, hipStream_t st) {
-    static bool attr_done[2] = {false, false};
-    g.tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = g.tiles_m * g.tiles_n;
-    ProfScope prof(amode == 0 ? PK_LINEAR : PK_CONV, 2.0 * g.M * g.N * g.K, st);
-    if (amode == 0) {
-        if (!attr_done[0]) {
-            A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-            attr_done[0] = true;
-        }
-        hipLaunchKernelGGL(gemm_kernel<0>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
-    } else {
-        if (!attr_done[1]) {
-            A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-            attr_done[1] = true;
-        }
-        hipLaunchKernelGGL(gemm_kernel<1>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
+template <int AMODE, int BM, int BN, bool FULL, bool RELU_A>
+static int launch_variant(const GemmArgs& g, hipStream_t st) {
+    auto kern = gemm_kernel<AMODE, BM, BN, FULL, RELU_A>;
+    constexpr int lds = 2 * (BM + BN) * LDP * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
     }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(256), lds, st, g);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
+}
+
+// Tile choice: measured on MI355X (tools/gemm_lab.hip).  128x128 is the most efficient main loop
+// (~128 TFLOP/s) but the chip holds 512 such workgroups at a time; below ~400 tiles smaller tiles win.
+static void choose_tile(int M, int N, int groups, int* bm, int* bn) {
+    auto blocks = [&](int BM_, int BN_) { return (long)((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_) * groups; };
+    if (blocks(128, 128) >= 400) { *bm = 128; *bn = 128; }
+    else if (blocks(128, 64) >= 700) { *bm = 128; *bn = 64; }
+    else { *bm = 64; *bn = 64; }
+}
+
+static int launch_gemm(int amode, GemmArgs& g, hipStream_t st) {
+    int bm, bn;
+    choose_tile(g.M, g.N, g.groups, &bm, &bn);
+    if (const char* f = getenv("A3R_GEMM_TILE")) {      // developer override: "128x128" | "128x64" | "64x64"
+        int a = 0, b = 0;
+        if (sscanf(f, "%dx%d", &a, &b) == 2 && ((a == 128 && (b == 128 || b == 64)) || (a == 64 && b == 64))) { bm = a; bn = b; }
+    }
+    g.tiles_m = (g.M + bm - 1) / bm;
+    g.tiles_n = (g.N + bn - 1) / bn;
+    g.tiles_per_group = g.tiles_m * g.tiles_n;
+    const bool full = g.M % bm == 0 && g.N % bn == 0;
+    const bool relu = g.epi.relu_a != 0;
+    ProfScope prof(amode == 0 ? PK_LINEAR : PK_CONV, 2.0 * g.M * g.N * g.K * g.groups, st);
+#define A3R_TILE_DISPATCH(AM, FULLV, RELUV)                                                  \
+    do {                                                                                    \
+        if (bm == 128 && bn == 128) return launch_variant<AM, 128, 128, FULLV, RELUV>(g, st); \
+        if (bm == 128 && bn == 64) return launch_variant<AM, 128, 64, FULLV, RELUV>(g, st);   \
+        return launch_variant<AM, 64, 64, FULLV, RELUV>(g, st);                               \
+    } while (0)
+    if (amode == 0) {
+        if (full) A3R_TILE_DISPATCH(0, true, false);
+        A3R_TILE_DISPATCH(0, false, false);
+    } else {
+        if (relu) A3R_TILE_DISPATCH(1, false, true);
+        A3R_TILE_DISPATCH(1, false, false);
+    }
+#undef A3R_TILE_DISPATCH
 }
 
 static int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who) {
     if (!e) return A3R_OK;
     A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_PIXSHUF, "%s: unknown epilogue %d", who, e->epi);
-    if (e->epi == A3R_EPI_RESID || e->epi == A3R_EPI_RESID2) A3R_CHECK_ARG(e->resid, "%s: RESID epilogue without resid", who);
-    if (e->epi == A3R_EPI_RESID2) A3R_CHECK_ARG(e->resid2, "%s: RESID2 epilogue without resid2", who);
     if (e->epi == A3R_EPI_ROPE)
         A3R_CHECK_ARG(e->rope_cols % 64 == 0 && e->rope_cols <= N && e->tokens_per_image > 0 && e->grid_w > 0 &&
                           e->tokens_per_image % e->grid_w == 0 && e->rope_cos && e->rope_sin,
@@ -243,23 +293,42 @@ static int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who) 
     return A3R_OK;
 }
 
+static int check_group(const GroupPtrs& p, int epi, const char* who) {
+    A3R_CHECK_ARG(p.A && p.Wt && p.C, "%s: null pointer", who);
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.Wt)) & 15) == 0,
+                  "%s: x and w must be 16-byte aligned", who);
+    if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) A3R_CHECK_ARG(p.resid, "%s: RESID epilogue without resid", who);
+    if (epi == A3R_EPI_RESID2) A3R_CHECK_ARG(p.resid2, "%s: RESID2 epilogue without resid2", who);
+    return A3R_OK;
+}
+
 }  // namespace a3r
 using namespace a3r;
 
-extern "C" int a3r_linear(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K,
-                          const a3r_epilogue* epi, void* stream) {
-    A3R_CHECK_ARG(x && w && y, "a3r_linear: null pointer");
+extern "C" int a3r_linear_grouped(const a3r_group_ptrs* groups, int n_groups, int lda, int ldc, int M, int N, int K,
+                                  const a3r_epilogue* epi, void* stream) {
+    A3R_CHECK_ARG(groups && n_groups >= 1 && n_groups <= 4, "a3r_linear_grouped: 1..4 groups required");
     A3R_CHECK_ARG(M > 0 && N > 0 && K > 0, "a3r_linear: M, N, K must be positive (got %d, %d, %d)", M, N, K);
     A3R_CHECK_ARG(K % BK == 0, "a3r_linear: K (%d) must be a multiple of %d", K, BK);
     A3R_CHECK_ARG(lda >= K && lda % 4 == 0 && ldc >= 1, "a3r_linear: bad leading dimensions lda=%d ldc=%d", lda, ldc);
-    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0,
-                  "a3r_linear: x and w must be 16-byte aligned");
     if (int rc = check_epilogue(epi, M, N, "a3r_linear")) return rc;
     GemmArgs g = {};
-    g.A = x; g.lda = lda; g.Wt = w; g.C = y; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     if (epi) g.epi = *epi;
+    A3R_CHECK_ARG(!g.epi.relu_a, "a3r_linear: relu_a is only available on a3r_conv3x3");
+    for (int i = 0; i < n_groups; i++) {
+        g.grp[i] = {groups[i].x, groups[i].w, groups[i].y, groups[i].bias, groups[i].resid, groups[i].resid2};
+        if (int rc = check_group(g.grp[i], g.epi.epi, "a3r_linear")) return rc;
+    }
+    g.groups = n_groups;
+    g.lda = lda; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     if (g.epi.epi != A3R_EPI_PIXSHUF) A3R_CHECK_ARG(ldc >= N, "a3r_linear: ldc (%d) < N (%d)", ldc, N);
     return launch_gemm(0, g, as_stream(stream));
+}
+
+extern "C" int a3r_linear(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K,
+                          const a3r_epilogue* epi, void* stream) {
+    a3r_group_ptrs p = {x, w, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr};
+    return a3r_linear_grouped(&p, 1, lda, ldc, M, N, K, epi, stream);
 }
 
 extern "C" int a3r_conv3x3(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout,
@@ -272,10 +341,13 @@ extern "C" int a3r_conv3x3(const float* x, const float* wp, float* y, int B, int
     g.cH = H; g.cW = W; g.cCin = Cin; g.cStride = stride;
     g.cHo = (H + 2 - 3) / stride + 1;
     g.cWo = (W + 2 - 3) / stride + 1;
-    g.A = x; g.lda = 0; g.Wt = wp; g.C = y; g.ldc = Cout;
+    g.lda = 0; g.ldc = Cout;
     g.M = B * g.cHo * g.cWo; g.N = Cout; g.K = 9 * Cin;
     if (int rc = check_epilogue(epi, g.M, g.N, "a3r_conv3x3")) return rc;
     if (epi) g.epi = *epi;
     A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF && g.epi.epi != A3R_EPI_ROPE, "a3r_conv3x3: unsupported epilogue");
+    g.groups = 1;
+    g.grp[0] = {x, wp, y, g.epi.bias, g.epi.resid, g.epi.resid2};
+    if (int rc = check_group(g.grp[0], g.epi.epi, "a3r_conv3x3")) return rc;
     return launch_gemm(1, g, as_stream(stream));
 }

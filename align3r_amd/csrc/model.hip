@@ -333,6 +333,15 @@ struct Plan {
         traced("linear", M, N, K);
         rc = a3r_linear(x, lda, w, y, ldc, M, N, K, &e, stream);
     }
+    // the same-shape projection of both decoders (dec_blocks[i] on view 1, dec_blocks2[i] on view 2) in one launch
+    void linear2(const float* x0, const float* x1, int lda, const float* w0, const float* w1, const float* b0, const float* b1,
+                 float* y0, float* y1, int ldc, int M, int N, int K, a3r_epilogue e, const float* r0 = nullptr,
+                 const float* r1 = nullptr) {
+        if (skip()) return;
+        traced("linear2", M, N, K);
+        a3r_group_ptrs g[2] = {{x0, w0, y0, b0, r0, nullptr}, {x1, w1, y1, b1, r1, nullptr}};
+        rc = a3r_linear_grouped(g, 2, lda, ldc, M, N, K, &e, stream);
+    }
     void ln(const float* x, const float* w, const float* b, float* y, int M, int D) {
         if (skip()) return;
         traced("layernorm", M, D);
@@ -478,29 +487,40 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             else if (level == hook_b) nxt = fbuf[3];
             else { nxt = (cur == fbuf[0]) ? fbuf[1] : fbuf[0]; }
             (void)next_free;
-            for (int s = 0; s < 2; s++) {
-                const BlockW& w = s ? m->dec2[i] : m->dec1[i];
-                const float* x_in = cur + (size_t)s * BN * D;
-                const float* y_in = cur + (size_t)(1 - s) * BN * D;
-                float* x_out = nxt + (size_t)s * BN * D;
-                float* xn_s = xn + (size_t)s * BN * D;
-                float* yn_s = yn + (size_t)s * BN * D;
-                float* qkv_s = qkv + (size_t)s * BN * 3 * D;
-                float* q_s = qb + (size_t)s * BN * D;
-                float* kv_s = kv + (size_t)s * BN * 2 * D;
-                float* att_s = att + (size_t)s * BN * D;
-                float* hid_s = hid + (size_t)s * BN * hidden;
+            {
+                // both decoders advance together: side s reads x = cur[s], y = cur[1-s] (model.py:218-220) and
+                // every same-shape projection of the two sides is one grouped launch.
+                const BlockW& w0 = m->dec1[i];
+                const BlockW& w1 = m->dec2[i];
+                const size_t S = (size_t)BN * D;                   // side stride in a [2*BN, D] buffer
+                const float *x0 = cur, *x1 = cur + S;
+                float *o0 = nxt, *o1 = nxt + S;
                 // x = x + attn(norm1(x))                                   blocks.py:187
-                P.self_block(w, x_out, x_in, BN, D, c.dec_num_heads, N, nw, hidden, xn_s, qkv_s, att_s, hid_s);
+                P.ln(x0, w0.n1w, w0.n1b, xn, BN, D);
+                P.ln(x1, w1.n1w, w1.n1b, xn + S, BN, D);
+                P.linear2(xn, xn + S, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, qkv + 3 * S, 3 * D, BN, 3 * D, D,
+                          P.rope_epi(nullptr, 2 * D, N, nw));
+                P.attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, 2 * B, c.dec_num_heads, N, N);
+                P.linear2(att, att + S, D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
+                          P.epi(A3R_EPI_RESID, nullptr), x0, x1);
                 // y_ = norm_y(y); x = x + cross_attn(norm2(x), y_, y_)     blocks.py:188-189
-                P.ln(y_in, w.nyw, w.nyb, yn_s, BN, D);
-                P.ln(x_out, w.n2w, w.n2b, xn_s, BN, D);
-                P.linear(xn_s, D, w.qw, q_s, D, BN, D, D, P.rope_epi(w.qb, D, N, nw));
-                P.linear(yn_s, D, w.kvw, kv_s, 2 * D, BN, 2 * D, D, P.rope_epi(w.kvb, D, N, nw));
-                P.attn(q_s, D, kv_s, 2 * D, kv_s + D, 2 * D, att_s, D, B, c.dec_num_heads, N, N);
-                P.linear(att_s, D, w.cprojw, x_out, D, BN, D, D, P.epi(A3R_EPI_RESID, w.cprojb, x_out));
+                P.ln(x1, w0.nyw, w0.nyb, yn, BN, D);               // side 0 attends to view 2's tokens
+                P.ln(x0, w1.nyw, w1.nyb, yn + S, BN, D);
+                P.ln(o0, w0.n2w, w0.n2b, xn, BN, D);
+                P.ln(o1, w1.n2w, w1.n2b, xn + S, BN, D);
+                P.linear2(xn, xn + S, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, qb + S, D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
+                P.linear2(yn, yn + S, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, kv + 2 * S, 2 * D, BN, 2 * D, D,
+                          P.rope_epi(nullptr, D, N, nw));
+                P.attn(qb, D, kv, 2 * D, kv + D, 2 * D, att, D, 2 * B, c.dec_num_heads, N, N);
+                P.linear2(att, att + S, D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
+                          P.epi(A3R_EPI_RESID, nullptr), o0, o1);
                 // x = x + mlp(norm3(x))                                    blocks.py:190
-                P.mlp(w, w.n3w, w.n3b, x_out, BN, D, hidden, xn_s, hid_s);
+                P.ln(o0, w0.n3w, w0.n3b, xn, BN, D);
+                P.ln(o1, w1.n3w, w1.n3b, xn + S, BN, D);
+                P.linear2(xn, xn + S, D, w0.fc1w, w1.fc1w, w0.fc1b, w1.fc1b, hid, hid + (size_t)BN * hidden, hidden, BN, hidden, D,
+                          P.epi(A3R_EPI_GELU, nullptr));
+                P.linear2(hid, hid + (size_t)BN * hidden, hidden, w0.fc2w, w1.fc2w, w0.fc2b, w1.fc2b, o0, o1, D, BN, D, hidden,
+                          P.epi(A3R_EPI_RESID, nullptr), o0, o1);
             }
             if (i < npc) {   // model.py:223-226
                 P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, hidden, xn, qkv, att, hid);

@@ -94,6 +94,24 @@ def linear(x, w, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
     return out
 
 
+def linear_grouped(xs, ws, biases, epi=_lib.EPI_NONE, resids=None, **kw):
+    """Several same-shape nn.Linear problems in one launch (a3r_linear_grouped)."""
+    G = len(xs)
+    K = xs[0].shape[-1]
+    M = xs[0].numel() // K
+    N = ws[0].shape[0]
+    outs = [torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32) for x in xs]
+    arr = (_lib.GroupPtrs * G)()
+    for i in range(G):
+        _req(xs[i], "x"); _req(ws[i], "w")
+        arr[i].x, arr[i].w, arr[i].y = xs[i].data_ptr(), ws[i].data_ptr(), outs[i].data_ptr()
+        arr[i].bias = None if biases is None else biases[i].data_ptr()
+        arr[i].resid = None if resids is None else resids[i].data_ptr()
+    e = make_epilogue(epi, **kw)
+    check(_lib.load().a3r_linear_grouped(arr, G, K, N, M, N, K, C.byref(e), stream_ptr()), "linear_grouped")
+    return outs
+
+
 def pack_conv3x3(w):
     Cout, Cin = w.shape[:2]
     wp = torch.empty((Cout, 3, 3, Cin), device=w.device, dtype=torch.float32)

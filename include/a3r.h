@@ -83,7 +83,7 @@ typedef struct {
     const float* bias;    /* [N] or NULL */
     const float* resid;   /* [M, ldc] for RESID/RESID2 */
     const float* resid2;  /* [M, ldc] for RESID2 */
-    int relu_a;           /* apply relu to the A operand while loading (RCU pre-activation dpt_block.py:131,136) */
+    int relu_a;           /* a3r_conv3x3 only: relu on the input while staging it (RCU pre-activation dpt_block.py:131,136) */
     /* ROPE */
     int rope_cols;        /* leading output columns to rotate (multiple of 64) */
     int tokens_per_image; /* N tokens; row r has token index r % N */
@@ -98,6 +98,20 @@ typedef struct {
  * (K % 32 == 0, lda % 4 == 0).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products. */
 int a3r_linear(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K,
                const a3r_epilogue* epi, void* stream);
+
+/* Up to 4 same-shape nn.Linear problems in ONE launch (e.g. the two decoders' projections, model.py:218-220):
+ * per-problem operands, shared M/N/K, leading dimensions and epilogue kind (epi->bias/resid/resid2 are ignored,
+ * the per-group pointers are used instead). */
+typedef struct {
+    const float* x;
+    const float* w;
+    float* y;
+    const float* bias;
+    const float* resid;
+    const float* resid2;
+} a3r_group_ptrs;
+int a3r_linear_grouped(const a3r_group_ptrs* groups, int n_groups, int lda, int ldc, int M, int N, int K,
+                       const a3r_epilogue* epi, void* stream);
 
 /* nn.Conv2d(k=3, padding=1, stride in {1,2}) on channels-last x [B, H, W, Cin] with PACKED weights
  * wp [Cout, 3, 3, Cin] (a3r_pack_conv3x3 from the checkpoint layout [Cout, Cin, 3, 3]); Cin % 32 == 0.

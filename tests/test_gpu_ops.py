@@ -48,7 +48,46 @@ def test_linear_epilogues(ops):
     out = r.clone()      # in-place residual (resid aliases the output)
     ops.linear(x, w, b, epi=_lib.EPI_RESID, resid=out, out=out)
     assert rel_err(cpu(out), cpu(lin + r.double())) < TOL
-    assert rel_err(cpu(ops.linear(x, w, None, relu_a=True)), cpu(torch.nn.functional.linear(torch.relu(x).double(), w.double()))) < TOL
+    with pytest.raises(RuntimeError, match="relu_a"):
+        ops.linear(x, w, None, relu_a=True)
+
+
+@pytest.mark.parametrize("tile", ["128x128", "128x64", "64x64"])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1000, 384, 128)])
+def test_linear_every_tile_shape(ops, monkeypatch, tile, M, N, K):
+    """The launcher picks the tile by grid fill; force each variant (full and ragged) through the same check."""
+    from align3r_amd import _lib
+    monkeypatch.setenv("A3R_GEMM_TILE", tile)
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert rel_err(cpu(ops.linear(x, w, b)), cpu(ref)) < TOL
+    assert rel_err(cpu(ops.linear(x, w, b, epi=_lib.EPI_GELU)), cpu(torch.nn.functional.gelu(ref))) < TOL
+    if N % 64 == 0:
+        gw = 5
+        ntok = 25 if M % 25 == 0 else gw
+        cos, sin = ops.rope_tables(x.device)
+        y = ops.linear(x, w, b, epi=_lib.EPI_ROPE, rope=(N, ntok, gw, cos, sin))
+        from oracle import model_np as O
+        lin = cpu(ref).astype(np.float32)
+        H = N // 64
+        Bn = M // ntok if M % ntok == 0 else None
+        if Bn:
+            pos = np.stack([np.arange(ntok) // gw, np.arange(ntok) % gw], -1)[None].repeat(Bn, 0)
+            want = O.rope2d(lin.reshape(Bn, ntok, H, 64).transpose(0, 2, 1, 3), pos).transpose(0, 2, 1, 3).reshape(M, N)
+            assert rel_err(cpu(y), want) < TOL
+
+
+def test_linear_grouped(ops):
+    from align3r_amd import _lib
+    M, N, K = 384, 192, 64
+    xs = [rnd(M, K, seed=i) for i in range(2)]
+    ws = [rnd(N, K, seed=10 + i, scale=K ** -0.5) for i in range(2)]
+    bs = [rnd(N, seed=20 + i) for i in range(2)]
+    rs = [rnd(M, N, seed=30 + i) for i in range(2)]
+    outs = ops.linear_grouped(xs, ws, bs, epi=_lib.EPI_RESID, resids=rs)
+    for i in range(2):
+        ref = torch.nn.functional.linear(xs[i].double(), ws[i].double(), bs[i].double()) + rs[i].double()
+        assert rel_err(cpu(outs[i]), cpu(ref)) < TOL
 
 
 def test_linear_rope_epilogue_matches_reference_rope(ops):

@@ -56,7 +56,7 @@ def test_argument_validation_without_gpu():
     assert lib.a3r_model_forward(h, *([None] * 4), 1, 64, 64, *([None] * 4), None, 0, None) != 0
     _lib.check(lib.a3r_model_destroy(h))
     assert lib.a3r_align_workspace_bytes(84, 16, 196608) > 0
-    assert lib.a3r_linear(None, 0, None, None, 0, 1, 1, 32, None, None) != 0
+    assert lib.a3r_linear(None, 32, None, None, 1, 1, 1, 32, None, None) != 0
     assert b"null pointer" in lib.a3r_last_error()
 
 
