@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liba3r.so")
+LIB_PATH = os.environ.get("A3R_LIB", os.path.join(_HERE, "lib", "liba3r.so"))   # A3R_LIB: developer override
 
 c_float_p = C.POINTER(C.c_float)
 c_void = C.c_void_p

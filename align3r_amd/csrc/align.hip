@@ -139,12 +139,63 @@ __global__ __launch_bounds__(TPB) void align_prep_kernel(AlignDev d) {
 
 // ------------------------------------------------------------------------------------------- main
 // grid (nchunks, N).  MODE 0: loss only; 1: gradients to g_depth (no update); 2: Adam update in place.
-template <bool MONO, bool L2, int MODE>
-__global__ __launch_bounds__(TPB) void align_main_kernel(AlignDev d, AdamArgs ad, float* g_depth) {
+// VEC (P % 4 == 0): a thread owns 4 CONSECUTIVE pixels, so one edge-side is three 16-byte loads of points and
+// one of weights per thread, and the next edge-side's loads are issued before the current one is consumed
+// (two register buffers) -- the kernel is latency-bound otherwise (12 waves/CU x 4 KB in flight).
+// !VEC: ragged P, pixels strided by the workgroup size, scalar loads.
+// Raw loaded registers of one (edge, side); nothing may TOUCH them between the load and consume(), or the
+// compiler has to wait for the data right where it was issued and the prefetch is gone.
+template <bool VEC> struct EdgeData;
+template <> struct EdgeData<true> { f32x4 a, b, c, w; };                    // 4 consecutive pixels: xyz xyz xyz xyz, wwww
+template <> struct EdgeData<false> { float x[PXT][3]; float w[PXT]; };
+
+__device__ __forceinline__ void load_edge(const AlignDev& d, int code, int P, int pix0, const bool* valid, EdgeData<true>& o) {
+    const int e = code >> 1, side = code & 1;
+    const float* X = (side ? d.pred_j : d.pred_i) + (size_t)e * P * 3;
+    const float* Wt = (side ? d.w_j : d.w_i) + (size_t)e * P;
+    const int p = valid[0] ? pix0 : 0;     // the 4 pixels are valid together (P % 4 == 0)
+    const f32x4* xp = reinterpret_cast<const f32x4*>(X + (size_t)p * 3);
+    o.a = xp[0]; o.b = xp[1]; o.c = xp[2];
+    o.w = *reinterpret_cast<const f32x4*>(Wt + p);
+}
+__device__ __forceinline__ void load_edge(const AlignDev& d, int code, int P, int pix0, const bool* valid, EdgeData<false>& o) {
+    const int e = code >> 1, side = code & 1;
+    const float* X = (side ? d.pred_j : d.pred_i) + (size_t)e * P * 3;
+    const float* Wt = (side ? d.w_j : d.w_i) + (size_t)e * P;
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const size_t pp = valid[i] ? pix0 + i * TPB : 0;
+        o.x[i][0] = X[pp * 3 + 0]; o.x[i][1] = X[pp * 3 + 1]; o.x[i][2] = X[pp * 3 + 2];
+        o.w[i] = Wt[pp];
+    }
+}
+__device__ __forceinline__ void unpack_edge(const EdgeData<true>& e, float (*x)[3], float* w) {
+    x[0][0] = e.a.x; x[0][1] = e.a.y; x[0][2] = e.a.z;
+    x[1][0] = e.a.w; x[1][1] = e.b.x; x[1][2] = e.b.y;
+    x[2][0] = e.b.z; x[2][1] = e.b.w; x[2][2] = e.c.x;
+    x[3][0] = e.c.y; x[3][1] = e.c.z; x[3][2] = e.c.w;
+    w[0] = e.w.x; w[1] = e.w.y; w[2] = e.w.z; w[3] = e.w.w;
+}
+__device__ __forceinline__ void unpack_edge(const EdgeData<false>& e, float (*x)[3], float* w) {
+#pragma unroll
+    for (int i = 0; i < PXT; i++) { x[i][0] = e.x[i][0]; x[i][1] = e.x[i][1]; x[i][2] = e.x[i][2]; w[i] = e.w[i]; }
+}
+
+#ifndef A3R_ALIGN_MIN_WAVES
+#define A3R_ALIGN_MIN_WAVES 1
+#endif
+template <bool MONO, bool L2, int MODE, bool VEC>
+__global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
+    AlignDev d, AdamArgs ad, float* g_depth,
+    // read-only, wave-uniform tables as noalias kernel arguments: the compiler can then use SCALAR loads
+    // (s_load), which do not sit on the vector-memory counter -- with vector loads every lookup of the next
+    // edge id drained the prefetched edge data (s_waitcnt vmcnt(0)) and serialised the loop
+    const int* __restrict__ inc_ptr, const int* __restrict__ inc, const float* __restrict__ edge_xf,
+    const float* __restrict__ img_xf, const int* __restrict__ imw, const int* __restrict__ imarea) {
     __shared__ float red[2][EB][16][16];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = d.P;
-    const float* ix = d.img_xf + n * 16;
+    const float* ix = img_xf + n * 16;
     float R[9], T[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -152,95 +203,133 @@ __global__ __launch_bounds__(TPB) void align_main_kernel(AlignDev d, AdamArgs ad
         T[r] = ix[r * 4 + 3];
     }
     const float f = ix[12], ppx = ix[13], ppy = ix[14], shift = ix[15];
-    const float inv_f = 1.f / f;   // only used for the gradient side; forward divides like the reference
-    const int W = d.imw[n], area = d.imarea[n];
+    const int W = imw[n], area = imarea[n];
+    const float invW = 1.f / (float)W, inv_f = 1.f / f;
+    const int pix0 = chunk * CHUNK + (VEC ? tid * PXT : tid);       // pixel i of this thread: pix0 + i * PSTEP
+    constexpr int PSTEP = VEC ? 1 : TPB;
 
-    float raw[PXT], dep[PXT], ddp[PXT], gxm[PXT], gym[PXT], rel[PXT][3], proj[PXT][3], gp[PXT][3];
+    // forward of the image side: depth -> camera point -> world point (optimizer.py:190-200,244-251)
+    auto pixel_forward = [&](int i, float rawv, float monov, float& dep, float& ddp, float& gxm, float& gym, float* rel) {
+        const int p = pix0 + i * PSTEP;
+        float gx = 0.f, gy = 0.f;
+        if (p < area) {
+            int y = (int)((float)p * invW);          // p < 2^24: exact up to +-1, fixed below
+            int x = p - y * W;
+            if (x < 0) { y--; x += W; }
+            if (x >= W) { y++; x -= W; }
+            gx = (float)x; gy = (float)y;
+        }
+        if (MONO) {
+            const float es = expf(rawv);
+            dep = monov * es + shift;
+            ddp = monov * es;
+        } else {
+            dep = expf(rawv);
+            ddp = dep;
+        }
+        gxm = gx - ppx; gym = gy - ppy;
+        rel[0] = dep * gxm * inv_f;  // optimizer.py:251: depth * (pixel_grid - pp) / focal  (1/f: one IEEE divide per thread)
+        rel[1] = dep * gym * inv_f;
+        rel[2] = dep;
+    };
+
+    float raw[PXT], monov[PXT], proj[PXT][3], gp[PXT][3];
     bool valid[PXT];
 #pragma unroll
-    for (int i = 0; i < PXT; i++) {
-        const int p = chunk * CHUNK + i * TPB + tid;
-        valid[i] = p < P;
-        const size_t off = (size_t)n * P + (valid[i] ? p : 0);
-        raw[i] = valid[i] ? d.depth[off] : 0.f;
-        float gx = 0.f, gy = 0.f;
-        if (p < area) { gx = (float)(p % W); gy = (float)(p / W); }
-        if (MONO) {
-            const float es = expf(raw[i]), m = valid[i] ? d.mono[off] : 0.f;
-            dep[i] = m * es + shift;
-            ddp[i] = m * es;
-        } else {
-            dep[i] = expf(raw[i]);
-            ddp[i] = dep[i];
+    for (int i = 0; i < PXT; i++) valid[i] = pix0 + i * PSTEP < P;
+    if (VEC) {
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f}, m4 = {0.f, 0.f, 0.f, 0.f};
+        if (valid[0]) {
+            r4 = *reinterpret_cast<const f32x4*>(d.depth + (size_t)n * P + pix0);
+            if (MONO) m4 = *reinterpret_cast<const f32x4*>(d.mono + (size_t)n * P + pix0);
         }
-        gxm[i] = gx - ppx; gym[i] = gy - ppy;
-        rel[i][0] = dep[i] * gxm[i] / f;      // optimizer.py:251: depth * (pixel_grid - pp) / focal
-        rel[i][1] = dep[i] * gym[i] / f;
-        rel[i][2] = dep[i];
+        raw[0] = r4.x; raw[1] = r4.y; raw[2] = r4.z; raw[3] = r4.w;
+        monov[0] = m4.x; monov[1] = m4.y; monov[2] = m4.z; monov[3] = m4.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const size_t off = (size_t)n * P + (valid[i] ? pix0 + i * PSTEP : 0);
+            raw[i] = valid[i] ? d.depth[off] : 0.f;
+            monov[i] = (MONO && valid[i]) ? d.mono[off] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        float dep, ddp, gxm, gym, rel[3];
+        pixel_forward(i, raw[i], monov[i], dep, ddp, gxm, gym, rel);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            proj[i][r] = R[r * 3] * rel[i][0] + R[r * 3 + 1] * rel[i][1] + R[r * 3 + 2] * rel[i][2] + T[r];
+            proj[i][r] = R[r * 3] * rel[0] + R[r * 3 + 1] * rel[1] + R[r * 3 + 2] * rel[2] + T[r];
             gp[i][r] = 0.f;
         }
     }
 
-    const int kbeg = d.inc_ptr[n], kend = d.inc_ptr[n + 1];
+    // one (edge, side): residuals, loss, gradient w.r.t. the world point, per-edge sums (12 + loss)
+    auto consume = [&](int code, const EdgeData<VEC>& ed, int buf, int kb) {
+        float ex[PXT][3], ew[PXT];
+        unpack_edge(ed, ex, ew);
+        const int e = code >> 1, side = code & 1;
+        const float* M = edge_xf + e * 16;
+        const float m00 = M[0], m01 = M[1], m02 = M[2], m03 = M[3];
+        const float m10 = M[4], m11 = M[5], m12 = M[6], m13 = M[7];
+        const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
+        const float inva = side ? d.inv_area_j : d.inv_area_i;
+        float acc[13];
+#pragma unroll
+        for (int j = 0; j < 13; j++) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const float x0 = ex[i][0], x1 = ex[i][1], x2 = ex[i][2], w = valid[i] ? ew[i] : 0.f;
+            const float r0 = proj[i][0] - (m00 * x0 + m01 * x1 + m02 * x2 + m03);
+            const float r1 = proj[i][1] - (m10 * x0 + m11 * x1 + m12 * x2 + m13);
+            const float r2 = proj[i][2] - (m20 * x0 + m21 * x1 + m22 * x2 + m23);
+            const float sq = r0 * r0 + r1 * r1 + r2 * r2;
+            float cf;
+            if (L2) {
+                acc[12] += sq * w * inva;
+                cf = 2.f * w * inva;
+            } else {
+                // v_rsq_f32 (1 ulp) instead of an IEEE sqrt + an IEEE divide: this loop is VALU-bound (PMC:
+                // 68 % VALU-active at 4 TB/s), and the two expansions were a quarter of its instructions
+                const float inv = sq > 0.f ? __builtin_amdgcn_rsqf(sq) : 0.f;
+                const float wa = w * inva;
+                acc[12] += sq * inv * wa;
+                cf = wa * inv;
+            }
+            if (MODE != 0) {
+                const float g0 = cf * r0, g1 = cf * r1, g2 = cf * r2;
+                gp[i][0] += g0; gp[i][1] += g1; gp[i][2] += g2;
+                acc[0] += g0 * x0; acc[1] += g0 * x1; acc[2] += g0 * x2;
+                acc[3] += g1 * x0; acc[4] += g1 * x1; acc[5] += g1 * x2;
+                acc[6] += g2 * x0; acc[7] += g2 * x1; acc[8] += g2 * x2;
+                acc[9] += g0; acc[10] += g1; acc[11] += g2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 13; j++) {
+            if (MODE == 0 && j < 12) continue;
+            const float s = dpp_row_sum16(acc[j]);
+            if ((lane & 15) == 0) red[buf][kb][wave * 4 + (lane >> 4)][j] = s;
+        }
+    };
+
+    const int kbeg = inc_ptr[n], kend = inc_ptr[n + 1];
     int buf = 0;
+    EdgeData<VEC> ea, eb;
+    if (kbeg < kend) load_edge(d, inc[kbeg], P, pix0, valid, ea);
     for (int k0 = kbeg; k0 < kend; k0 += EB) {
 #pragma unroll 1
-        for (int kb = 0; kb < EB; kb++) {
+        for (int kb = 0; kb < EB; kb += 2) {
             const int k = k0 + kb;
             if (k >= kend) break;
-            const int code = d.inc[k];
-            const int e = code >> 1, side = code & 1;
-            const float* M = d.edge_xf + e * 16;
-            const float m00 = M[0], m01 = M[1], m02 = M[2], m03 = M[3];
-            const float m10 = M[4], m11 = M[5], m12 = M[6], m13 = M[7];
-            const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
-            const float* X = (side ? d.pred_j : d.pred_i) + (size_t)e * P * 3;
-            const float* Wt = (side ? d.w_j : d.w_i) + (size_t)e * P;
-            const float inva = side ? d.inv_area_j : d.inv_area_i;
-            float acc[13];
-#pragma unroll
-            for (int j = 0; j < 13; j++) acc[j] = 0.f;
-            float x0[PXT], x1[PXT], x2[PXT], w[PXT];
-#pragma unroll
-            for (int i = 0; i < PXT; i++) {
-                const int p = chunk * CHUNK + i * TPB + tid;
-                const size_t pp = valid[i] ? p : 0;
-                x0[i] = X[pp * 3 + 0]; x1[i] = X[pp * 3 + 1]; x2[i] = X[pp * 3 + 2];
-                w[i] = valid[i] ? Wt[pp] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < PXT; i++) {
-                const float r0 = proj[i][0] - (m00 * x0[i] + m01 * x1[i] + m02 * x2[i] + m03);
-                const float r1 = proj[i][1] - (m10 * x0[i] + m11 * x1[i] + m12 * x2[i] + m13);
-                const float r2 = proj[i][2] - (m20 * x0[i] + m21 * x1[i] + m22 * x2[i] + m23);
-                const float sq = r0 * r0 + r1 * r1 + r2 * r2;
-                float cf;
-                if (L2) {
-                    acc[12] += sq * w[i] * inva;
-                    cf = 2.f * w[i] * inva;
-                } else {
-                    const float rho = sqrtf(sq);
-                    acc[12] += rho * w[i] * inva;
-                    cf = rho > 0.f ? w[i] / rho * inva : 0.f;
-                }
-                if (MODE != 0) {
-                    const float g0 = cf * r0, g1 = cf * r1, g2 = cf * r2;
-                    gp[i][0] += g0; gp[i][1] += g1; gp[i][2] += g2;
-                    acc[0] += g0 * x0[i]; acc[1] += g0 * x1[i]; acc[2] += g0 * x2[i];
-                    acc[3] += g1 * x0[i]; acc[4] += g1 * x1[i]; acc[5] += g1 * x2[i];
-                    acc[6] += g2 * x0[i]; acc[7] += g2 * x1[i]; acc[8] += g2 * x2[i];
-                    acc[9] += g0; acc[10] += g1; acc[11] += g2;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 13; j++) {
-                if (MODE == 0 && j < 12) continue;
-                const float s = dpp_row_sum16(acc[j]);
-                if ((lane & 15) == 0) red[buf][kb][wave * 4 + (lane >> 4)][j] = s;
-            }
+            const int code0 = inc[k];
+            const bool has1 = k + 1 < kend;
+            const int code1 = has1 ? inc[k + 1] : code0;
+            if (has1) load_edge(d, code1, P, pix0, valid, eb);          // in flight while `ea` is consumed
+            consume(code0, ea, buf, kb);
+            if (!has1) break;
+            if (k + 2 < kend) load_edge(d, inc[k + 2], P, pix0, valid, ea);
+            consume(code1, eb, buf, kb + 1);
         }
         __syncthreads();
         if (tid < EB * 16) {
@@ -256,37 +345,60 @@ __global__ __launch_bounds__(TPB) void align_main_kernel(AlignDev d, AdamArgs ad
     }
     if (MODE == 0) return;
 
-    // per-image sums and the per-pixel parameter
-    float accN[16];
+    // per-image sums and the per-pixel parameter (forward quantities are recomputed: cheaper than keeping them live)
+    float accN[16], gout[PXT];
 #pragma unroll
     for (int j = 0; j < 16; j++) accN[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < PXT; i++) {
+        float dep, ddp, gxm, gym, rel[3];
+        pixel_forward(i, raw[i], monov[i], dep, ddp, gxm, gym, rel);
         const float h0 = R[0] * gp[i][0] + R[3] * gp[i][1] + R[6] * gp[i][2];
         const float h1 = R[1] * gp[i][0] + R[4] * gp[i][1] + R[7] * gp[i][2];
         const float h2 = R[2] * gp[i][0] + R[5] * gp[i][1] + R[8] * gp[i][2];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            accN[r * 3 + 0] += gp[i][r] * rel[i][0];
-            accN[r * 3 + 1] += gp[i][r] * rel[i][1];
-            accN[r * 3 + 2] += gp[i][r] * rel[i][2];
+            accN[r * 3 + 0] += gp[i][r] * rel[0];
+            accN[r * 3 + 1] += gp[i][r] * rel[1];
+            accN[r * 3 + 2] += gp[i][r] * rel[2];
             accN[9 + r] += gp[i][r];
         }
-        const float gd = h0 * gxm[i] * inv_f + h1 * gym[i] * inv_f + h2;
-        accN[12] += -(h0 * rel[i][0] + h1 * rel[i][1]) / d.focal_break;
-        accN[13] += -h0 * dep[i] * inv_f * 10.f;
-        accN[14] += -h1 * dep[i] * inv_f * 10.f;
+        const float gd = h0 * gxm * inv_f + h1 * gym * inv_f + h2;
+        accN[12] += -(h0 * rel[0] + h1 * rel[1]) / d.focal_break;
+        accN[13] += -h0 * dep * inv_f * 10.f;
+        accN[14] += -h1 * dep * inv_f * 10.f;
         accN[15] += gd;
-        const float g = gd * ddp[i];
-        const int p = chunk * CHUNK + i * TPB + tid;
-        if (valid[i]) {
-            const size_t off = (size_t)n * P + p;
+        gout[i] = gd * ddp;
+    }
+    const size_t NP = (size_t)d.N * P;
+    if (VEC) {
+        if (valid[0]) {
+            const size_t off = (size_t)n * P + pix0;
             if (MODE == 1) {
-                g_depth[off] = g;
+                f32x4 g4 = {gout[0], gout[1], gout[2], gout[3]};
+                *reinterpret_cast<f32x4*>(g_depth + off) = g4;
             } else {
-                const size_t NP = (size_t)d.N * P;
+                f32x4 m4 = *reinterpret_cast<const f32x4*>(d.adam_depth + off);
+                f32x4 v4 = *reinterpret_cast<const f32x4*>(d.adam_depth + NP + off);
+                float pm[4] = {m4.x, m4.y, m4.z, m4.w}, pv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4];
+#pragma unroll
+                for (int i = 0; i < PXT; i++) { pp[i] = raw[i]; adam_update(pp[i], gout[i], pm[i], pv[i], ad); }
+                f32x4 o0 = {pp[0], pp[1], pp[2], pp[3]}, o1 = {pm[0], pm[1], pm[2], pm[3]}, o2 = {pv[0], pv[1], pv[2], pv[3]};
+                *reinterpret_cast<f32x4*>(d.depth + off) = o0;
+                *reinterpret_cast<f32x4*>(d.adam_depth + off) = o1;
+                *reinterpret_cast<f32x4*>(d.adam_depth + NP + off) = o2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            if (!valid[i]) continue;
+            const size_t off = (size_t)n * P + pix0 + i * PSTEP;
+            if (MODE == 1) {
+                g_depth[off] = gout[i];
+            } else {
                 float m = d.adam_depth[off], v = d.adam_depth[NP + off], pv = raw[i];
-                adam_update(pv, g, m, v, ad);
+                adam_update(pv, gout[i], m, v, ad);
                 d.depth[off] = pv; d.adam_depth[off] = m; d.adam_depth[NP + off] = v;
             }
         }
@@ -312,19 +424,29 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b < d.E) {
         const int e = b;
-        double s[13];
-        for (int j = 0; j < 13; j++) s[j] = 0.0;
+        // 4 lanes per chunk row: lane = 4*c' + q reads floats [4q, 4q+4) of chunk c' (16-byte loads), fixed order
+        f32x4 part = {0.f, 0.f, 0.f, 0.f};
+        const int q = lane & 3;
         for (int side = 0; side < 2; side++) {
             const int k = d.slot_of[e * 2 + side];
-            const float* pe = d.partE + (size_t)k * d.nchunks * 16;
-            for (int c = lane; c < d.nchunks; c += 64)
-                for (int j = loss_only ? 12 : 0; j < 13; j++) s[j] += (double)pe[c * 16 + j];
+            const f32x4* pe = reinterpret_cast<const f32x4*>(d.partE + (size_t)k * d.nchunks * 16);
+            for (int c = lane >> 2; c < d.nchunks; c += 16) {
+                const f32x4 v = pe[c * 4 + q];
+                part += v;
+            }
         }
-        for (int j = loss_only ? 12 : 0; j < 13; j++) {
-            double v = s[j];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            s[j] = v;
+        // sum over the 16 lanes that share q (lanes q, q+4, ...): xor 4, 8, 16, 32
+        float pv[4] = {part.x, part.y, part.z, part.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float v = pv[t];
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            pv[t] = v;
         }
+        // lane q now holds totals of floats 4q..4q+3; gather the 13 used values to every lane
+        double s[13];
+#pragma unroll
+        for (int j = 0; j < 13; j++) s[j] = (double)__shfl(pv[j & 3], j >> 2);
         if (lane == 0) {
             d.lossE[e] = (float)s[12];
             if (!loss_only) {
@@ -352,16 +474,20 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
         }
     } else if (!loss_only) {
         const int n = b - d.E;
-        double s[16];
-        for (int j = 0; j < 16; j++) s[j] = 0.0;
-        const float* pn = d.partN + (size_t)n * d.nchunks * 16;
-        for (int c = lane; c < d.nchunks; c += 64)
-            for (int j = 0; j < 16; j++) s[j] += (double)pn[c * 16 + j];
-        for (int j = 0; j < 16; j++) {
-            double v = s[j];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            s[j] = v;
+        f32x4 part = {0.f, 0.f, 0.f, 0.f};
+        const int q = lane & 3;
+        const f32x4* pn = reinterpret_cast<const f32x4*>(d.partN + (size_t)n * d.nchunks * 16);
+        for (int c = lane >> 2; c < d.nchunks; c += 16) part += pn[c * 4 + q];
+        float pv[4] = {part.x, part.y, part.z, part.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float v = pv[t];
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            pv[t] = v;
         }
+        double s[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) s[j] = (double)__shfl(pv[j & 3], j >> 2);
         if (lane == 0) {
             const float* p = d.im_poses + n * 7;
             float R[9], qn[4], nrm;
@@ -566,13 +692,20 @@ static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, hipS
     // algorithmic bytes of one iteration: 32 B per edge-pixel + 24 B per image-pixel (+4 mono)
     const double bytes = 32.0 * a->d.E * a->d.P + (MODE == 2 ? 24.0 : 4.0) * a->d.N * a->d.P + (a->use_mono ? 4.0 * a->d.N * a->d.P : 0.0);
     ProfScope prof(PK_ALIGN_MAIN, bytes, st);
+    const bool vec = a->d.P % 4 == 0;
+#define A3R_ALIGN_LAUNCH(MONOV, L2V)                                                                                      \
+    do {                                                                                                                 \
+        if (vec) hipLaunchKernelGGL((align_main_kernel<MONOV, L2V, MODE, true>), grid, block, 0, st, a->d, ad, g_depth,   \
+                                    a->d.inc_ptr, a->d.inc, a->d.edge_xf, a->d.img_xf, a->d.imw, a->d.imarea);          \
+        else hipLaunchKernelGGL((align_main_kernel<MONOV, L2V, MODE, false>), grid, block, 0, st, a->d, ad, g_depth,     \
+                                a->d.inc_ptr, a->d.inc, a->d.edge_xf, a->d.img_xf, a->d.imw, a->d.imarea);              \
+    } while (0)
     if (a->use_mono) {
-        if (a->dist_l2) hipLaunchKernelGGL((align_main_kernel<true, true, MODE>), grid, block, 0, st, a->d, ad, g_depth);
-        else hipLaunchKernelGGL((align_main_kernel<true, false, MODE>), grid, block, 0, st, a->d, ad, g_depth);
+        if (a->dist_l2) A3R_ALIGN_LAUNCH(true, true); else A3R_ALIGN_LAUNCH(true, false);
     } else {
-        if (a->dist_l2) hipLaunchKernelGGL((align_main_kernel<false, true, MODE>), grid, block, 0, st, a->d, ad, g_depth);
-        else hipLaunchKernelGGL((align_main_kernel<false, false, MODE>), grid, block, 0, st, a->d, ad, g_depth);
+        if (a->dist_l2) A3R_ALIGN_LAUNCH(false, true); else A3R_ALIGN_LAUNCH(false, false);
     }
+#undef A3R_ALIGN_LAUNCH
 }
 
 extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {

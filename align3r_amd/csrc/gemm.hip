@@ -240,13 +240,20 @@ static int launch_variant(const GemmArgs& g, hipStream_t st) {
     return A3R_OK;
 }
 
-// Tile choice: measured on MI355X (tools/gemm_lab.hip).  128x128 is the most efficient main loop
-// (~128 TFLOP/s) but the chip holds 512 such workgroups at a time; below ~400 tiles smaller tiles win.
+// Tile choice.  Workgroups resident on a CU share its MFMA pipes, so a launch of n equal workgroups takes about
+// ceil(n / 256) workgroup-times whatever the residency; the cost of a tile shape is therefore
+// ceil(n / 256) * BM * BN / eff, with the main-loop efficiencies measured on MI355X (tools/gemm_lab.hip:
+// 131 / 119 / 113 TFLOP/s at 4096^3 for 128x128 / 128x64 / 64x64).  The model reproduces the measured winner
+// on every ViT-L shape of the pair forward.
 static void choose_tile(int M, int N, int groups, int* bm, int* bn) {
-    auto blocks = [&](int BM_, int BN_) { return (long)((M + BM_ - 1) / BM_) * ((N + BN_ - 1) / BN_) * groups; };
-    if (blocks(128, 128) >= 400) { *bm = 128; *bn = 128; }
-    else if (blocks(128, 64) >= 700) { *bm = 128; *bn = 64; }
-    else { *bm = 64; *bn = 64; }
+    static const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const double eff[3] = {1.0, 0.91, 0.86};
+    double best = 1e300;
+    for (int t = 0; t < 3; t++) {
+        const long n = (long)((M + tiles[t][0] - 1) / tiles[t][0]) * ((N + tiles[t][1] - 1) / tiles[t][1]) * groups;
+        const double cost = (double)((n + 255) / 256) * tiles[t][0] * tiles[t][1] / eff[t];
+        if (cost < best * 0.999) { best = cost; *bm = tiles[t][0]; *bn = tiles[t][1]; }
+    }
 }
 
 static int launch_gemm(int amode, GemmArgs& g, hipStream_t st) {

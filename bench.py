@@ -36,9 +36,9 @@ FLOP_PER_PAIR = {(384, 512): 1969.1e9, (288, 512): 1436.1e9, (224, 224): 461.2e9
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=7, help="default 7 x 12 pairs = the 84 pairs of the clip")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="frame pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=12, help="frame pairs per step and per GPU")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--frames", type=int, default=16)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused aligner iteration (developer tool): config-2/3-like sizes."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from align3r_amd import _lib
+from align3r_amd.aligner import AlignEngine
+from align3r_amd.dust3r.image_pairs import make_pairs
+
+def run(N, H, W, graph, mono, iters=100):
+    pairs = make_pairs([dict(idx=i) for i in range(N)], graph, symmetrize=True)
+    edges = [(a["idx"], b["idx"]) for a, b in pairs]
+    E, P = len(edges), H * W
+    g = torch.Generator(device="cuda").manual_seed(2)
+    dev = "cuda"
+    pi = torch.randn(E, P, 3, generator=g, device=dev); pj = torch.randn(E, P, 3, generator=g, device=dev)
+    wi = torch.log(1 + 9 * torch.rand(E, P, generator=g, device=dev)); wj = torch.log(1 + 9 * torch.rand(E, P, generator=g, device=dev))
+    m = (0.5 + 3 * torch.rand(N, P, generator=g, device=dev)) if mono else None
+    al = AlignEngine([i for i, j in edges], [j for i, j in edges], pi, pj, wi, wj, [(H, W)] * N, mono=m, device=dev, loss_capacity=iters + 16)
+    al.set_params(pw_poses=torch.randn(E, 8, generator=g, device=dev), depth=torch.randn(N, P, generator=g, device=dev) / 10 - (0 if mono else 3),
+                  im_poses=torch.randn(N, 7, generator=g, device=dev), im_focals=torch.full((N,), 20 * float(np.log(max(H, W)))))
+    al.run(5, 0.05, total_iters=iters + 5)
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    losses = al.run(iters, 0.05, first_iter=5, total_iters=iters + 5)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    r = _lib.prof_report()
+    main, small = r[5], r[6]
+    print(f"N={N} E={E} P={P} mono={mono}: {iters/dt:8.1f} it/s  main {1e3*main['ms']/main['launches']:7.1f} us  "
+          f"{main['work']/main['ms']/1e6:7.1f} GB/s  small {1e3*small['ms']/max(small['launches'],1):6.1f} us  loss {losses[0]:.4f}->{losses[-1]:.4f}", flush=True)
+
+if __name__ == "__main__":
+    run(16, 384, 512, "swin-3-noncyclic", False)
+    run(16, 384, 512, "swin-3-noncyclic", True)
+    run(32, 288, 512, "complete", False, iters=30)
