@@ -65,8 +65,11 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # A3R_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, barrier, all-reduce) with a single rank too
+    use_dist = world > 1 or os.environ.get("A3R_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     H, W, B = a.height, a.width, a.batch
@@ -92,16 +95,16 @@ def main():
     flat = torch.empty(B * P * 8, device=dev)                      # one step's outputs, contiguous for the collective
     out = dict(pts3d_1=flat[:B * P * 3].view(B, H, W, 3), pts3d_2=flat[B * P * 3:B * P * 6].view(B, H, W, 3),
                conf_1=flat[B * P * 6:B * P * 7].view(B, H, W), conf_2=flat[B * P * 7:].view(B, H, W))
-    gathered = torch.empty(world * B * P * 8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B * P * 8, device=dev) if use_dist else None
 
     def step(s):
         eng.forward(*inputs[s % n_batches], out=out)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, flat)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -116,7 +119,7 @@ def main():
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
     prof = _lib.prof_report()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -203,7 +206,7 @@ def main():
             res["cpu_baseline"]["align_sample"] = f"5 iterations of oracle/align_ref.c (OpenMP) at N={a.frames}, E={E}, P={P}"
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
