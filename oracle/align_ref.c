@@ -318,3 +318,177 @@ int a3r_oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* =================================================================================================
+ * cloud_opt_flow extras (dust3r/cloud_opt_flow/optimizer.py:500-572)
+ * ================================================================================================= */
+
+/* relative_pose_loss (optimizer.py:559-572) summed over consecutive image poses:
+ *   sum_n ||R_n^T R_{n+1} - I||_F + tw * ||R_n^T (t_{n+1} - t_n)||,  RT = _get_poses(im_poses)
+ * Returns the (unweighted) loss and ADDS weight * gradient to g_im_poses [N,7]. */
+double a3r_oracle_temporal_loss_grad(int N, const float* im_poses, float translation_weight, float weight,
+                                     float* g_im_poses) {
+    double total = 0;
+    double* GR = calloc((size_t)N * 9, sizeof(double));
+    double* Gt = calloc((size_t)N * 3, sizeof(double));
+    float* R = malloc(sizeof(float) * N * 9);
+    float* T = malloc(sizeof(float) * N * 3);
+    float* qn = malloc(sizeof(float) * N * 4);
+    float* nr = malloc(sizeof(float) * N);
+    for (int n = 0; n < N; n++) {
+        quat_to_R(im_poses + n * 7, R + n * 9, qn + n * 4, nr + n);
+        for (int k = 0; k < 3; k++) T[n * 3 + k] = signed_expm1f(im_poses[n * 7 + 4 + k]);
+    }
+    for (int n = 0; n + 1 < N; n++) {
+        const float *Ra = R + n * 9, *Rb = R + (n + 1) * 9;
+        double M[9], a = 0;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += (double)Ra[k * 3 + i] * Rb[k * 3 + j];   /* (Ra^T Rb)_ij */
+                M[i * 3 + j] = s - (i == j);
+                a += M[i * 3 + j] * M[i * 3 + j];
+            }
+        a = sqrt(a);
+        double d[3], u[3], un = 0;
+        for (int k = 0; k < 3; k++) d[k] = (double)T[(n + 1) * 3 + k] - T[n * 3 + k];
+        for (int i = 0; i < 3; i++) {
+            u[i] = Ra[0 * 3 + i] * d[0] + Ra[1 * 3 + i] * d[1] + Ra[2 * 3 + i] * d[2];
+            un += u[i] * u[i];
+        }
+        un = sqrt(un);
+        total += a + translation_weight * un;
+        if (a > 0) {      /* dL/dRa = Rb G^T, dL/dRb = Ra G with G = M / a */
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double sa = 0, sb = 0;
+                    for (int k = 0; k < 3; k++) {
+                        sa += (double)Rb[i * 3 + k] * M[j * 3 + k] / a;
+                        sb += (double)Ra[i * 3 + k] * M[k * 3 + j] / a;
+                    }
+                    GR[n * 9 + i * 3 + j] += sa;
+                    GR[(n + 1) * 9 + i * 3 + j] += sb;
+                }
+        }
+        if (un > 0) {
+            double gu[3], Rg[3];
+            for (int i = 0; i < 3; i++) gu[i] = translation_weight * u[i] / un;
+            for (int i = 0; i < 3; i++) Rg[i] = Ra[i * 3 + 0] * gu[0] + Ra[i * 3 + 1] * gu[1] + Ra[i * 3 + 2] * gu[2];
+            for (int i = 0; i < 3; i++) {
+                Gt[(n + 1) * 3 + i] += Rg[i];
+                Gt[n * 3 + i] -= Rg[i];
+                for (int j = 0; j < 3; j++) GR[n * 9 + i * 3 + j] += d[i] * gu[j];   /* u = Ra^T d */
+            }
+        }
+    }
+    for (int n = 0; n < N; n++) {
+        double gq[4];
+        quat_backward(qn + n * 4, nr[n], GR + n * 9, gq);
+        for (int k = 0; k < 4; k++) g_im_poses[n * 7 + k] += (float)(weight * gq[k]);
+        for (int k = 0; k < 3; k++)
+            g_im_poses[n * 7 + 4 + k] += (float)(weight * Gt[n * 3 + k] * signed_expm1_grad(im_poses[n * 7 + 4 + k]));
+    }
+    free(GR); free(Gt); free(R); free(T); free(qn); free(nr);
+    return total;
+}
+
+/* Ego-flow loss (optimizer.py:521-541; DepthBasedWarping/warp_by_disp goem_opt.py:195-236; smooth_L1_loss_fn :18-24).
+ * Direction 0: source ei -> target ej compared with flow_ij, direction 1: source ej -> target ei with flow_ji.
+ *   disp = 1/(depth+1e-6); X = r/disp with r = K_s^-1 (x,y,1); Y = R_t^T (R_s X + T_s - T_t);
+ *   n = disp*K_t*Y normalised by (z + 1e-6); flow = n - (x,y); smooth-L1(beta=1) on flow*m vs gt*m with m = ~dynamic,
+ *   per element mask (loss < pxl_thre) * m; loss_dir = sum(loss*ppm)/sum(ppm).
+ * Pass 1 (scale == NULL): only sums[4] = {S_0, C_0, S_1, C_1}.
+ * Pass 2 (scale = {c_0, c_1}): ADDS c_dir * d(sum loss*ppm) to the gradient arrays (depth = log-depth parameter).
+ * focals [N] / pp [N,2] are the per-image VALUES (f, cx, cy); g_f [N] is d/df (value), g_ppv [N,2] d/d(cx,cy). */
+int a3r_oracle_flow_loss_grad(int E, int N, int H, int W, const int* ei, const int* ej, const float* flow_ij,
+                              const float* flow_ji, const unsigned char* dyn, const float* depth_param,
+                              const float* im_poses, const float* focals, const float* pp, float pxl_thre,
+                              const double* scale, double* sums, float* g_depth, float* g_im_poses, float* g_f,
+                              float* g_ppv) {
+    const int P = H * W;
+    float* R = malloc(sizeof(float) * N * 9);
+    float* T = malloc(sizeof(float) * N * 3);
+    float* qn = malloc(sizeof(float) * N * 4);
+    float* nr = malloc(sizeof(float) * N);
+    for (int n = 0; n < N; n++) {
+        quat_to_R(im_poses + n * 7, R + n * 9, qn + n * 4, nr + n);
+        for (int k = 0; k < 3; k++) T[n * 3 + k] = signed_expm1f(im_poses[n * 7 + 4 + k]);
+    }
+    double* GR = calloc((size_t)N * 9, sizeof(double));
+    double* GT = calloc((size_t)N * 3, sizeof(double));
+    double* Gf = calloc(N, sizeof(double));
+    double* Gpp = calloc((size_t)N * 2, sizeof(double));
+    double* Gd = scale ? calloc((size_t)N * P, sizeof(double)) : NULL;
+    sums[0] = sums[1] = sums[2] = sums[3] = 0;
+    for (int e = 0; e < E; e++)
+        for (int dir = 0; dir < 2; dir++) {
+            const int s = dir ? ej[e] : ei[e], t = dir ? ei[e] : ej[e];
+            const float* fl = (dir ? flow_ji : flow_ij) + (size_t)e * 2 * P;
+            const float *Rs = R + s * 9, *Rt = R + t * 9, *Ts = T + s * 3, *Tt = T + t * 3;
+            const double fs = focals[s], ft = focals[t], cxs = pp[s * 2], cys = pp[s * 2 + 1], cxt = pp[t * 2], cyt = pp[t * 2 + 1];
+            const double c = scale ? scale[dir] : 0.0;
+            double S = 0, C = 0;
+            for (int p = 0; p < P; p++) {
+                if (dyn[(size_t)s * P + p]) continue;                    /* mask = ~dynamic_mask of the source image */
+                const double x = p % W, y = p / W;
+                const double dep = exp((double)depth_param[(size_t)s * P + p]);
+                const double dp = dep + 1e-6;                            /* 1/disp */
+                const double r[3] = {(x - cxs) / fs, (y - cys) / fs, 1.0};
+                double Xs[3] = {dp * r[0], dp * r[1], dp}, Pw[3], v[3], Y[3];
+                for (int i = 0; i < 3; i++) Pw[i] = Rs[i * 3] * Xs[0] + Rs[i * 3 + 1] * Xs[1] + Rs[i * 3 + 2] * Xs[2] + Ts[i];
+                for (int i = 0; i < 3; i++) v[i] = Pw[i] - Tt[i];
+                for (int i = 0; i < 3; i++) Y[i] = Rt[0 * 3 + i] * v[0] + Rt[1 * 3 + i] * v[1] + Rt[2 * 3 + i] * v[2];
+                const double qx = ft * Y[0] + cxt * Y[2], qy = ft * Y[1] + cyt * Y[2], qz = Y[2] + 1e-6 * dp;
+                const double est[2] = {qx / qz - x, qy / qz - y};
+                double gn[2] = {0, 0};
+                for (int k = 0; k < 2; k++) {
+                    const double dlt = est[k] - fl[(size_t)k * P + p], ad = fabs(dlt);
+                    const double l = ad < 1.0 ? 0.5 * dlt * dlt : ad - 0.5;
+                    if (l < pxl_thre) {
+                        S += l; C += 1;
+                        gn[k] = ad < 1.0 ? dlt : (dlt > 0 ? 1.0 : -1.0);
+                    }
+                }
+                if (!scale || c == 0.0) continue;
+                const double gq[3] = {c * gn[0] / qz, c * gn[1] / qz, -c * (gn[0] * qx + gn[1] * qy) / (qz * qz)};
+                const double gY[3] = {ft * gq[0], ft * gq[1], cxt * gq[0] + cyt * gq[1] + gq[2]};
+                Gf[t] += gq[0] * Y[0] + gq[1] * Y[1];
+                Gpp[t * 2] += gq[0] * Y[2];
+                Gpp[t * 2 + 1] += gq[1] * Y[2];
+                double gPw[3];
+                for (int i = 0; i < 3; i++) gPw[i] = Rt[i * 3] * gY[0] + Rt[i * 3 + 1] * gY[1] + Rt[i * 3 + 2] * gY[2];
+                for (int i = 0; i < 3; i++) {
+                    GT[t * 3 + i] -= gPw[i];
+                    GT[s * 3 + i] += gPw[i];
+                    for (int j = 0; j < 3; j++) {
+                        GR[t * 9 + i * 3 + j] += v[i] * gY[j];            /* Y = Rt^T v */
+                        GR[s * 9 + i * 3 + j] += gPw[i] * Xs[j];          /* Pw = Rs Xs + Ts */
+                    }
+                }
+                double h[3];
+                for (int j = 0; j < 3; j++) h[j] = Rs[0 * 3 + j] * gPw[0] + Rs[1 * 3 + j] * gPw[1] + Rs[2 * 3 + j] * gPw[2];
+                const double gdp = h[0] * r[0] + h[1] * r[1] + h[2] + 1e-6 * gq[2];
+                Gd[(size_t)s * P + p] += gdp * dep;                      /* d/d(log depth) */
+                Gf[s] += -(h[0] * Xs[0] + h[1] * Xs[1]) / fs;
+                Gpp[s * 2] += -h[0] * dp / fs;
+                Gpp[s * 2 + 1] += -h[1] * dp / fs;
+            }
+            sums[dir * 2] += S;
+            sums[dir * 2 + 1] += C;
+        }
+    if (scale) {
+        for (size_t i = 0; i < (size_t)N * P; i++) g_depth[i] += (float)Gd[i];
+        for (int n = 0; n < N; n++) {
+            double gq[4];
+            quat_backward(qn + n * 4, nr[n], GR + n * 9, gq);
+            for (int k = 0; k < 4; k++) g_im_poses[n * 7 + k] += (float)gq[k];
+            for (int k = 0; k < 3; k++) g_im_poses[n * 7 + 4 + k] += (float)(GT[n * 3 + k] * signed_expm1_grad(im_poses[n * 7 + 4 + k]));
+            g_f[n] += (float)Gf[n];
+            g_ppv[n * 2] += (float)Gpp[n * 2];
+            g_ppv[n * 2 + 1] += (float)Gpp[n * 2 + 1];
+        }
+        free(Gd);
+    }
+    free(R); free(T); free(qn); free(nr); free(GR); free(GT); free(Gf); free(Gpp);
+    return 0;
+}

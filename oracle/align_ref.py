@@ -51,12 +51,37 @@ def linear_schedule(t, lr_start, lr_end):   # commons.py:128-130
     return lr_start + (lr_end - lr_start) * t
 
 
+def cycled_linear_schedule(t, lr_start, lr_end, num_cycles=2):   # cloud_opt_flow/commons.py:97-103
+    cycle_t = t * num_cycles
+    cycle_t = cycle_t - int(cycle_t)
+    if t == 1:
+        cycle_t = 1
+    return linear_schedule(cycle_t, lr_start, lr_end)
+
+
+def schedule_lr(schedule, t, lr, lr_min):
+    """lr of global_alignment_iter (cloud_opt/base_opt.py:451-457, cloud_opt_flow/base_opt.py:554-566)."""
+    if schedule == "cosine":
+        return cosine_schedule(t, lr, lr_min)
+    if schedule == "linear":
+        return linear_schedule(t, lr, lr_min)
+    if schedule.startswith("cycle"):
+        try:
+            n = int(schedule[5:])
+        except ValueError:
+            n = 2
+        return cycled_linear_schedule(t, lr, lr_min, num_cycles=n)
+    raise ValueError(f"bad lr schedule={schedule!r}")
+
+
 class AlignOracle:
     """State + loop of PointCloudOptimizer (optimizer.py:22-71, base_opt.py:424-464), all-numpy/C."""
 
     def __init__(self, ei, ej, pred_i, pred_j, w_i, w_j, imshapes, mono=None, base_scale=0.5, pw_break=20.0,
                  focal_break=20.0, norm_pw_scale=True, dist="l1", train_poses=True, train_focals=True,
-                 train_pp=False):
+                 train_pp=False, shared_focal=False, temporal_smoothing_weight=0.0, translation_weight=0.1, flow=None):
+        """flow (cloud_opt_flow only): dict(flow_ij [E,2,P], flow_ji [E,2,P], dyn [N,P] bool, weight, thre, start_epoch,
+        num_total_iter, pxl_thre) -- optimizer.py:36-116,521-541."""
         E, P = w_i.shape
         N = len(imshapes)
         self.E, self.N, self.P = E, N, P
@@ -75,11 +100,23 @@ class AlignOracle:
         self.params = {}
         self.adam = {}
         self.step_count = 0
+        self.shared_focal = bool(shared_focal)
+        self.tsw, self.trans_w = float(temporal_smoothing_weight), float(translation_weight)
+        self.flow = None
+        self.flow_dropped = False
+        if flow is not None and flow.get("weight", 0) > 0:
+            assert mono is None and len(set(imshapes)) == 1
+            self.flow = dict(flow)
+            self.flow["flow_ij"] = np.ascontiguousarray(flow["flow_ij"], np.float32).reshape(E, 2, P)
+            self.flow["flow_ji"] = np.ascontiguousarray(flow["flow_ji"], np.float32).reshape(E, 2, P)
+            self.flow["dyn"] = np.ascontiguousarray(flow["dyn"]).reshape(N, P).astype(np.uint8)
+        self.hw = imshapes[0]
 
     def set_params(self, pw_poses, depth, im_poses, im_focals, shifts=None, im_pp=None, pw_adaptors=None):
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).copy()
         self.params = dict(pw_poses=f32(pw_poses).reshape(self.E, 8), depth=f32(depth).reshape(self.N, self.P),
-                           im_poses=f32(im_poses).reshape(self.N, 7), im_focals=f32(im_focals).reshape(self.N),
+                           im_poses=f32(im_poses).reshape(self.N, 7),
+                           im_focals=f32(im_focals).reshape(-1)[:1] if self.shared_focal else f32(im_focals).reshape(self.N),
                            shifts=f32(shifts if shifts is not None else np.zeros(self.N)).reshape(self.N),
                            im_pp=f32(im_pp if im_pp is not None else np.zeros((self.N, 2))).reshape(self.N, 2),
                            pw_adaptors=f32(pw_adaptors if pw_adaptors is not None else np.zeros((self.E, 2))))
@@ -98,20 +135,61 @@ class AlignOracle:
             t.append("im_pp")
         return t
 
-    def loss_grad(self):
+    def _focals_full(self):
+        f = self.params["im_focals"]
+        return np.ascontiguousarray(np.repeat(f, self.N) if self.shared_focal else f, dtype=np.float32)
+
+    def loss_grad(self, epoch=9999):
         p = self.params
         g = {k: np.zeros_like(p[k]) for k in self.trainable()}
+        focals_full = self._focals_full()
+        g_focals_full = np.zeros(self.N, np.float32)
+        if "im_poses" not in g:
+            g_poses = np.zeros_like(p["im_poses"])
+        else:
+            g_poses = g["im_poses"]
+        g_pp = g["im_pp"] if "im_pp" in g else np.zeros_like(p["im_pp"])
         loss = C.c_double(0)
         lib().a3r_oracle_align_loss_grad(
             C.byref(self.cfg), _p(self.ei, C.c_int), _p(self.ej, C.c_int), _p(self.imw, C.c_int),
             _p(self.imarea, C.c_int), _p(self.pred_i), _p(self.pred_j), _p(self.w_i), _p(self.w_j), _p(self.mono),
             _p(self.pp0), _p(p["pw_poses"]), _p(p["pw_adaptors"]), _p(p["depth"]), _p(p["shifts"]), _p(p["im_poses"]),
-            _p(p["im_focals"]), _p(p["im_pp"]), C.byref(loss), _p(g.get("pw_poses")), _p(g.get("depth")),
-            _p(g.get("shifts")), _p(g.get("im_poses")), _p(g.get("im_focals")), _p(g.get("im_pp")))
-        return loss.value, g
+            _p(focals_full), _p(p["im_pp"]), C.byref(loss), _p(g.get("pw_poses")), _p(g.get("depth")),
+            _p(g.get("shifts")), _p(g_poses), _p(g_focals_full), _p(g_pp))
+        total = loss.value
+        # --- cloud_opt_flow extras (optimizer.py:516-555)
+        if self.tsw > 0:
+            L = lib().a3r_oracle_temporal_loss_grad
+            L.restype = C.c_double
+            total += self.tsw * L(self.N, _p(p["im_poses"]), C.c_float(self.trans_w), C.c_float(self.tsw), _p(g_poses))
+        fl = self.flow
+        if fl is not None and epoch >= fl["num_total_iter"] * fl["start_epoch"]:
+            H, W = self.hw
+            fvals = np.exp(focals_full / self.cfg.focal_break).astype(np.float32)
+            ppv = (self.pp0 + 10 * p["im_pp"]).astype(np.float32)
+            sums = (C.c_double * 4)()
+            args = (self.E, self.N, H, W, _p(self.ei, C.c_int), _p(self.ej, C.c_int), _p(fl["flow_ij"]), _p(fl["flow_ji"]),
+                    fl["dyn"].ctypes.data_as(C.POINTER(C.c_ubyte)), _p(p["depth"]), _p(p["im_poses"]), _p(fvals), _p(ppv),
+                    C.c_float(fl["pxl_thre"]))
+            lib().a3r_oracle_flow_loss_grad(*args, None, sums, None, None, None, None)
+            flow_loss = sums[0] / sums[1] + sums[2] / sums[3]
+            if flow_loss > fl["thre"] and fl["thre"] > 0:            # optimizer.py:538-540
+                self.flow_dropped = True
+            else:
+                total += fl["weight"] * flow_loss
+                scale = (C.c_double * 2)(fl["weight"] / sums[1], fl["weight"] / sums[3])
+                g_fv = np.zeros(self.N, np.float32)
+                g_ppv = np.zeros((self.N, 2), np.float32)
+                gd = g["depth"]
+                lib().a3r_oracle_flow_loss_grad(*args, scale, sums, _p(gd), _p(g_poses), _p(g_fv), _p(g_ppv))
+                g_focals_full += g_fv * fvals / self.cfg.focal_break
+                g_pp += 10 * g_ppv
+        if "im_focals" in g:
+            g["im_focals"][:] = g_focals_full.sum() if self.shared_focal else g_focals_full
+        return total, g
 
-    def step(self, lr, b1=0.9, b2=0.9, eps=1e-8):
-        loss, g = self.loss_grad()
+    def step(self, lr, b1=0.9, b2=0.9, eps=1e-8, epoch=9999):
+        loss, g = self.loss_grad(epoch)
         self.step_count += 1
         for k, gk in g.items():
             if k not in self.adam:
@@ -126,9 +204,7 @@ class AlignOracle:
         total = total_iters or niter
         losses = []
         for it in range(first_iter, first_iter + niter):
-            t = it / total
-            cur = cosine_schedule(t, lr, lr_min) if schedule == "cosine" else linear_schedule(t, lr, lr_min)
-            losses.append(self.step(float(cur)))
+            losses.append(self.step(float(schedule_lr(schedule, it / total, lr, lr_min)), epoch=it))
         return losses
 
     def pose_matrices(self):
@@ -138,5 +214,5 @@ class AlignOracle:
         f = np.zeros(self.N, np.float32)
         pp = np.zeros((self.N, 2), np.float32)
         lib().a3r_oracle_pose_matrices(C.byref(self.cfg), _p(p["pw_poses"]), _p(p["pw_adaptors"]), _p(p["im_poses"]),
-                                       _p(p["im_focals"]), _p(p["im_pp"]), _p(self.pp0), _p(eM), _p(iR), _p(f), _p(pp))
+                                       _p(self._focals_full()), _p(p["im_pp"]), _p(self.pp0), _p(eM), _p(iR), _p(f), _p(pp))
         return eM, iR, f, pp

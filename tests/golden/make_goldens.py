@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only -- /root/reference does not exist on the GPU box):
-    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align] [--out tests/golden]
+    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow] [--out tests/golden]
 
 What it does
   * puts /root/reference on sys.path (read-only, bytecode writing disabled) and imports the
@@ -111,6 +111,12 @@ def import_reference(aligner=False):
                   "evo.core.trajectory", "evo.tools", "evo.tools.file_interface", "evo.tools.plot"):
             _stub(n)
         _install_roma_standin()
+        # cloud_opt_flow only (optimizer.py:13-14, init_im_poses.py:22): optional third-party models, not on the path
+        _stub("seaborn")
+        _stub("sam2")
+        _stub("sam2.build_sam", build_sam2_video_predictor=None)
+        _stub("third_party")
+        _stub("third_party.raft", load_RAFT=None)
 
 
 def ref_model(cfg, img_size=(512, 512)):
@@ -398,14 +404,132 @@ def gen_align(out):
         json.dump(meta, f)
 
 
+def _flow_scene(N, H, W, seed):
+    """Geometric scene in the aligner's own conventions (integer pixel grid, pp = (W/2, H/2)): per-frame depth,
+    camera-to-world poses, pairwise pointmaps, ground-truth ego-flow between frames (+ noise and gross outliers),
+    dynamic masks.  Used for the cloud_opt_flow goldens."""
+    rng = np.random.default_rng(seed)
+    f = 1.1 * max(H, W)
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    rays = np.stack([(xs - W / 2) / f, (ys - H / 2) / f, np.ones_like(xs)], -1)
+    cams, depths, world = [], [], []
+    for n in range(N):
+        a = 0.04 * (n - (N - 1) / 2)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        t = np.array([0.15 * n, 0.02 * n, 0.03 * n])
+        d = 2.5 + 0.6 * np.sin(xs / W * 5 + n) * np.cos(ys / H * 3) + 0.1 * rng.random((H, W))
+        cams.append((R, t)); depths.append(d); world.append((rays * d[..., None]) @ R.T + t)
+    edges = [(i, j) for i in range(N) for j in range(N) if i != j and abs(i - j) <= 2]
+    E = len(edges)
+    p1 = np.empty((E, H, W, 3), np.float32); p2 = np.empty((E, H, W, 3), np.float32)
+    fij = np.empty((E, 2, H, W), np.float32); fji = np.empty((E, 2, H, W), np.float32)
+
+    def flow(src, tgt):
+        Rt, tt = cams[tgt]
+        Y = (world[src] - tt) @ Rt
+        u = f * Y[..., 0] / Y[..., 2] + W / 2
+        v = f * Y[..., 1] / Y[..., 2] + H / 2
+        fl = np.stack([u - xs, v - ys], 0) + 0.3 * rng.standard_normal((2, H, W))
+        out = rng.random((H, W)) < 0.03                       # gross outliers: beyond the per-pixel threshold
+        fl[:, out] += 80.0
+        return fl.astype(np.float32)
+    for e, (i, j) in enumerate(edges):
+        R, t = cams[i]
+        s = 0.5                                                # DUSt3R predictions live at an arbitrary scale
+        p1[e] = s * ((world[i] - t) @ R) + 0.01 * rng.standard_normal((H, W, 3))
+        p2[e] = s * ((world[j] - t) @ R) + 0.01 * rng.standard_normal((H, W, 3))
+        fij[e] = flow(i, j); fji[e] = flow(j, i)
+    c1 = (1 + 9 * rng.random((E, H, W))).astype(np.float32)
+    c2 = (1 + 9 * rng.random((E, H, W))).astype(np.float32)
+    dyn = rng.random((N, H, W)) < 0.1
+    return dict(edges=edges, p1=p1, p2=p2, c1=c1, c2=c2, flow_ij=fij, flow_ji=fji, dyn=dyn, cams=cams, depths=depths, f=f)
+
+
+def gen_alignflow(out):
+    """cloud_opt_flow.PointCloudOptimizer (cloud_opt_flow/optimizer.py:500-572): 3-D alignment + temporal smoothing
+    + ego-flow smooth-L1 loss, shared focal.  RAFT is not run: the flow fields / dynamic masks are injected
+    (they are inputs of the path)."""
+    from dust3r.cloud_opt_flow import global_aligner, GlobalAlignerMode
+    from dust3r.cloud_opt_flow.base_opt import global_alignment_iter
+    import contextlib, io
+    g, meta = {}, dict(cases=[])
+    cases = [  # tag, N, H, W, shared_focal, tsw, trans_w, flow_w, flow_thre, schedule, lr
+        ("flow_shared", 5, 24, 32, True, 0.01, 1.0, 0.01, 20.0, "linear", 0.01),
+        ("flow_perimg_thre", 4, 16, 24, False, 0.01, 0.1, 0.01, 0.05, "cosine", 0.01),   # tiny flow_loss_thre: the term gets dropped
+        ("smooth_only", 4, 16, 16, True, 0.05, 1.0, 0.0, 20.0, "cycle2", 0.02),
+    ]
+    for tag, N, H, W, shared, tsw, tw, fw, fthre, sched, lr in cases:
+        sc = _flow_scene(N, H, W, seed=3)
+        edges = sc["edges"]; E = len(edges)
+        view1 = dict(idx=[i for i, j in edges], true_shape=torch.tensor([[H, W]] * E),
+                     dynamic_mask=[torch.from_numpy(sc["dyn"][i]) for i, j in edges])
+        view2 = dict(idx=[j for i, j in edges], true_shape=torch.tensor([[H, W]] * E),
+                     dynamic_mask=[torch.from_numpy(sc["dyn"][j]) for i, j in edges])
+        pred1 = dict(pts3d=torch.from_numpy(sc["p1"]), conf=torch.from_numpy(sc["c1"]))
+        pred2 = dict(pts3d_in_other_view=torch.from_numpy(sc["p2"]), conf=torch.from_numpy(sc["c2"]))
+        torch.manual_seed(13)
+        niter = 50
+        net = global_aligner(dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2), "cpu", mode=GlobalAlignerMode.PointCloudOptimizer,
+                             verbose=False, min_conf_thr=3, shared_focal=shared, temporal_smoothing_weight=tsw, translation_weight=tw,
+                             flow_loss_weight=0.0, flow_loss_start_epoch=0.1, flow_loss_thre=fthre, num_total_iter=niter, pxl_thre=50)
+        # inject the flow inputs (the constructor would run RAFT, optimizer.py:104-116)
+        net.flow_loss_weight = fw
+        net.flow_ij = torch.from_numpy(sc["flow_ij"]); net.flow_ji = torch.from_numpy(sc["flow_ji"])
+        # start close to the true geometry (random poses put every pixel beyond the per-pixel flow threshold)
+        with torch.no_grad():
+            for n in range(N):
+                R, t = sc["cams"][n]
+                a = np.arctan2(R[0, 2], R[0, 0]) + 0.01 * np.sin(n + 1.0)
+                net.im_poses[n, 0:4] = torch.tensor([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)]) * 1.3     # un-normalised on purpose
+                tt = torch.tensor(t + 0.01 * np.cos(np.arange(3) + n), dtype=torch.float32)
+                net.im_poses[n, 4:7] = torch.sign(tt) * torch.log1p(tt.abs())
+                net.im_depthmaps[n] = torch.from_numpy(np.log(sc["depths"][n] * (1 + 0.02 * np.sin(np.arange(H * W).reshape(H, W) / 7.0))).reshape(-1)).float()
+            net.im_focals[:] = float(net.focal_break * np.log(sc["f"] * 1.02))
+        for k in ("p1", "p2", "c1", "c2", "flow_ij", "flow_ji", "dyn"):
+            g[f"{tag}_{k}"] = sc[k]
+        trainable = [n for n, p in net.named_parameters() if p.requires_grad]
+        for n, p in net.named_parameters():
+            if n in trainable or n in ("im_pp", "pw_adaptors"):
+                g[f"{tag}_init_{n}"] = p.detach().numpy().copy()
+        for epoch, et in ((9999, "on"), (0, "off")):
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss = net(epoch=epoch)
+            loss.backward()
+            g[f"{tag}_loss_{et}"] = np.float64(loss.item())
+            for n, p in net.named_parameters():
+                if n in trainable:
+                    g[f"{tag}_grad_{et}_{n}"] = p.grad.numpy().copy()
+                    p.grad = None
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.9))
+        losses = []
+        for it in range(niter):
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss, _ = global_alignment_iter(net, it, niter, lr, 1e-3, opt, sched)
+            losses.append(loss)
+            if it + 1 in (1, 5, 10, 50):
+                for n, p in net.named_parameters():
+                    if n in trainable:
+                        g[f"{tag}_k{it+1}_{n}"] = p.detach().numpy().copy()
+        g[f"{tag}_losses"] = np.asarray(losses, np.float64)
+        meta["cases"].append(dict(tag=tag, N=N, H=H, W=W, edges=edges, shared_focal=shared, temporal_smoothing_weight=tsw,
+                                  translation_weight=tw, flow_loss_weight=fw, flow_loss_thre=fthre, flow_loss_start_epoch=0.1,
+                                  pxl_thre=50, schedule=sched, lr=lr, lr_min=1e-3, niter=niter, trainable=trainable,
+                                  flow_dropped=bool(net.flow_loss_flag)))
+        print("alignflow", tag, g[f"{tag}_loss_on"], g[f"{tag}_loss_off"], "->", losses[-1], "dropped:", net.flow_loss_flag)
+    np.savez_compressed(os.path.join(out, "alignflow.npz"), **g)
+    with open(os.path.join(out, "alignflow.json"), "w") as f:
+        json.dump(meta, f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.set_num_threads(8)
-    todo = [a.only] if a.only else ["pairs", "ops", "tiny", "vitl", "align"]
-    import_reference(aligner="align" in todo)
+    todo = [a.only] if a.only else ["pairs", "ops", "tiny", "vitl", "align", "alignflow"]
+    import_reference(aligner=any(t.startswith("align") for t in todo))
     for t in todo:
         globals()[f"gen_{t}"](a.out)
 

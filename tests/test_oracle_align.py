@@ -67,3 +67,63 @@ def test_adam_trajectory(case, g):
             ref = g[f"{tag}_k{k}_{names[kk]}"]
             assert rel_err(o.params[kk].reshape(ref.shape), ref) < 1e-4, (k, kk)
     assert rel_err(np.asarray(losses), g[tag + "_losses"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------- cloud_opt_flow (a-14)
+FLOW_META = json.load(open(os.path.join(GOLDEN, "alignflow.json")))
+FLOW_NAMES = dict(pw_poses="pw_poses", depth="im_depthmaps", im_poses="im_poses", im_focals="im_focals")
+
+
+def build_flow(case, g, cls=AlignOracle, **kw):
+    tag, N, H, W = case["tag"], case["N"], case["H"], case["W"]
+    edges = case["edges"]
+    E, P = len(edges), H * W
+    fl = dict(flow_ij=g[tag + "_flow_ij"], flow_ji=g[tag + "_flow_ji"], dyn=g[tag + "_dyn"], weight=case["flow_loss_weight"],
+              thre=case["flow_loss_thre"], start_epoch=case["flow_loss_start_epoch"], num_total_iter=case["niter"],
+              pxl_thre=case["pxl_thre"])
+    o = cls([i for i, j in edges], [j for i, j in edges], g[tag + "_p1"], g[tag + "_p2"], np.log(g[tag + "_c1"]).reshape(E, P),
+            np.log(g[tag + "_c2"]).reshape(E, P), [(H, W)] * N, shared_focal=case["shared_focal"],
+            temporal_smoothing_weight=case["temporal_smoothing_weight"], translation_weight=case["translation_weight"], flow=fl, **kw)
+    o.set_params(g[tag + "_init_pw_poses"], g[tag + "_init_im_depthmaps"], g[tag + "_init_im_poses"], g[tag + "_init_im_focals"])
+    return o
+
+
+@pytest.fixture(scope="module")
+def gf():
+    return np.load(os.path.join(GOLDEN, "alignflow.npz"))
+
+
+@pytest.mark.parametrize("case", FLOW_META["cases"], ids=[c["tag"] for c in FLOW_META["cases"]])
+def test_flow_variant_loss_and_gradients(case, gf):
+    """cloud_opt_flow forward (3-D term + temporal smoothing + ego-flow smooth-L1, shared focal) vs the reference's
+    autograd, with the flow term active (epoch 9999) and before its start epoch (epoch 0)."""
+    o = build_flow(case, gf)
+    tag = case["tag"]
+    for et, epoch in (("on", 9999), ("off", 0)):
+        loss, gr = o.loss_grad(epoch)
+        assert abs(loss - gf[f"{tag}_loss_{et}"]) / gf[f"{tag}_loss_{et}"] < 1e-6
+        for k, v in gr.items():
+            ref = gf[f"{tag}_grad_{et}_{FLOW_NAMES[k]}"]
+            assert rel_err(v.reshape(ref.shape), ref) < 1e-5, (et, k)
+    if case["flow_loss_weight"] > 0 and not case["flow_dropped"]:
+        _, g_on = o.loss_grad(9999)
+        _, g_off = o.loss_grad(0)
+        for k in ("im_poses", "im_focals"):       # the flow term in isolation (its share of the total gradient is small)
+            ref = gf[f"{tag}_grad_on_{FLOW_NAMES[k]}"].astype(np.float64) - gf[f"{tag}_grad_off_{FLOW_NAMES[k]}"]
+            mine = (g_on[k].astype(np.float64) - g_off[k]).reshape(ref.shape)
+            assert rel_err(mine, ref) < 1e-4, k
+
+
+@pytest.mark.parametrize("case", FLOW_META["cases"], ids=[c["tag"] for c in FLOW_META["cases"]])
+def test_flow_variant_trajectory(case, gf):
+    o = build_flow(case, gf)
+    tag = case["tag"]
+    losses, done = [], 0
+    for k in (1, 5, 10, 50):
+        losses += o.run(k - done, case["lr"], case["schedule"], case["lr_min"], first_iter=done, total_iters=case["niter"])
+        done = k
+        for kk in o.trainable():
+            ref = gf[f"{tag}_k{k}_{FLOW_NAMES[kk]}"]
+            assert rel_err(o.params[kk].reshape(ref.shape), ref) < 1e-4, (k, kk)
+    assert rel_err(np.asarray(losses), gf[tag + "_losses"]) < 1e-5
+    assert o.flow_dropped == case["flow_dropped"]          # flow_loss > flow_loss_thre -> term dropped (optimizer.py:538-540)
