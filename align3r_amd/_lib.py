@@ -47,6 +47,13 @@ class AlignDesc(C.Structure):
                 ("loss_capacity", C.c_int)]
 
 
+class AlignFlowDesc(C.Structure):
+    _fields_ = [("shared_focal", C.c_int), ("temporal_smoothing_weight", C.c_float), ("translation_weight", C.c_float),
+                ("flow_loss_weight", C.c_float), ("flow_loss_thre", C.c_float), ("pxl_thre", C.c_float),
+                ("flow_start_iter", C.c_int), ("H", C.c_int), ("W", C.c_int), ("flow_ij", c_void), ("flow_ji", c_void),
+                ("dynamic_mask", c_void), ("workspace", c_void), ("workspace_bytes", C.c_size_t)]
+
+
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_RELU, EPI_ROPE, EPI_RESID2, EPI_PIXSHUF = range(7)
 
 # name -> (restype, argtypes); every symbol declared in include/a3r.h
@@ -83,6 +90,11 @@ SIGNATURES = {
     "a3r_align_step": (C.c_int, [c_void, C.c_float, c_void]),
     "a3r_align_loss": (C.c_int, [c_void, c_void, c_void]),
     "a3r_align_grad": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
+    "a3r_align_flow_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "a3r_align_set_flow": (C.c_int, [c_void, C.POINTER(AlignFlowDesc), c_void]),
+    "a3r_align_step_epoch": (C.c_int, [c_void, C.c_float, C.c_int, c_void]),
+    "a3r_align_grad_epoch": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_void]),
+    "a3r_align_flow_state": (C.c_int, [c_void, c_void]),
     "a3r_align_steps_done": (C.c_int, [c_void]),
     "a3r_align_invalidate": (C.c_int, [c_void]),
     "a3r_align_pose_matrices": (C.c_int, [c_void, c_void, c_void, c_void]),

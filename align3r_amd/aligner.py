@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AlignDesc, check, ptr, stream_ptr
+from ._lib import AlignDesc, AlignFlowDesc, check, ptr, stream_ptr
 
 
 def cosine_schedule(t, lr_start, lr_end):   # commons.py:123-125
@@ -25,10 +25,37 @@ def linear_schedule(t, lr_start, lr_end):   # commons.py:128-130
     return lr_start + (lr_end - lr_start) * t
 
 
+def cycled_linear_schedule(t, lr_start, lr_end, num_cycles=2):   # cloud_opt_flow/commons.py:97-103
+    assert 0 <= t <= 1
+    cycle_t = t * num_cycles
+    cycle_t = cycle_t - int(cycle_t)
+    if t == 1:
+        cycle_t = 1
+    return linear_schedule(cycle_t, lr_start, lr_end)
+
+
+def schedule_lr(schedule, t, lr, lr_min):
+    """Learning rate of global_alignment_iter (cloud_opt/base_opt.py:451-457, cloud_opt_flow/base_opt.py:554-566)."""
+    if schedule == "cosine":
+        return cosine_schedule(t, lr, lr_min)
+    if schedule == "linear":
+        return linear_schedule(t, lr, lr_min)
+    if schedule.startswith("cycle"):
+        try:
+            n = int(schedule[5:])
+        except ValueError:
+            n = 2
+        return cycled_linear_schedule(t, lr, lr_min, num_cycles=n)
+    raise ValueError(f"bad lr schedule={schedule!r}")
+
+
 class AlignEngine:
     def __init__(self, ei, ej, pred_i, pred_j, w_i, w_j, imshapes, mono=None, base_scale=0.5, pw_break=20.0,
                  focal_break=20.0, norm_pw_scale=True, dist="l1", train_poses=True, train_focals=True, train_pp=False,
-                 device="cuda:0", loss_capacity=4096):
+                 device="cuda:0", loss_capacity=4096, shared_focal=False, temporal_smoothing_weight=0.0,
+                 translation_weight=0.1, flow=None):
+        """flow (cloud_opt_flow variant): dict(flow_ij [E,2,P], flow_ji [E,2,P], dyn [N,P] bool, weight, thre, start_epoch,
+        num_total_iter, pxl_thre) -- the optical-flow fields and dynamic masks are inputs (optimizer.py:104-116)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -53,8 +80,21 @@ class AlignEngine:
                           train_focals=bool(train_focals), train_pp=bool(train_pp))
         self.base_scale, self.pw_break, self.focal_break = base_scale, pw_break, focal_break
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.shared_focal = bool(shared_focal)
+        self.tsw, self.trans_w = float(temporal_smoothing_weight), float(translation_weight)
+        self.flow = None
+        if flow is not None and flow.get("weight", 0) > 0:
+            if self.use_mono or len(set(self.imshapes)) != 1:
+                raise RuntimeError("the flow variant needs images of one shape and no mono-depth parameterisation")
+            self.flow = dict(flow)
+            self.flow["flow_ij"] = f32(flow["flow_ij"]).reshape(E, 2, P)
+            self.flow["flow_ji"] = f32(flow["flow_ji"]).reshape(E, 2, P)
+            self.flow["dyn"] = torch.as_tensor(np.ascontiguousarray(flow["dyn"])).reshape(N, P).to(dev, torch.uint8).contiguous()
+        self.flow_variant = self.shared_focal or self.tsw > 0 or self.flow is not None
         self.params = dict(pw_poses=z(E, 8), pw_adaptors=z(E, 2), depth=z(N, P), shifts=z(N), im_poses=z(N, 7),
-                           im_focals=z(N), im_pp=z(N, 2))
+                           im_focals=z(1 if self.shared_focal else N), im_pp=z(N, 2))
+        self.flow_workspace = (torch.empty(int(self.lib.a3r_align_flow_workspace_bytes(E, N, P)), dtype=torch.uint8, device=dev)
+                               if self.flow_variant else None)
         self.adam = dict(pw_poses=z(2, E, 8), depth=z(2, N, P), small=z(2, N, 16))
         self.loss_capacity = loss_capacity
         self.loss_history = z(loss_capacity)
@@ -90,6 +130,20 @@ class AlignEngine:
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.a3r_align_create(C.byref(d), C.byref(h), stream_ptr()), "a3r_align_create")
+            if self.flow_variant:
+                f = AlignFlowDesc()
+                f.shared_focal = int(self.shared_focal)
+                f.temporal_smoothing_weight, f.translation_weight = self.tsw, self.trans_w
+                if self.flow is not None:
+                    fl = self.flow
+                    f.flow_loss_weight, f.flow_loss_thre, f.pxl_thre = fl["weight"], fl["thre"], fl["pxl_thre"]
+                    bound = fl["num_total_iter"] * fl["start_epoch"]        # epoch >= num_total_iter * flow_loss_start_epoch
+                    f.flow_start_iter = next(e for e in range(0, 1 << 30) if e >= bound)
+                    f.H, f.W = self.imshapes[0]
+                    f.flow_ij, f.flow_ji = fl["flow_ij"].data_ptr(), fl["flow_ji"].data_ptr()
+                    f.dynamic_mask = fl["dyn"].data_ptr()
+                f.workspace, f.workspace_bytes = self.flow_workspace.data_ptr(), self.flow_workspace.numel()
+                check(self.lib.a3r_align_set_flow(h, C.byref(f), stream_ptr()), "a3r_align_set_flow")
         self.handle = h
 
     def __del__(self):
@@ -143,34 +197,41 @@ class AlignEngine:
             check(self.lib.a3r_align_loss(self.handle, ptr(out), stream_ptr()), "a3r_align_loss")
         return out
 
-    def loss_grad(self):
+    def loss_grad(self, epoch=9999):
         g_pw = torch.zeros_like(self.params["pw_poses"])
         g_depth = torch.zeros_like(self.params["depth"])
         g_small = torch.zeros(self.N, 16, device=self.device)
         loss = torch.zeros(1, device=self.device)
         with torch.cuda.device(self.device):
-            check(self.lib.a3r_align_grad(self.handle, ptr(g_pw), ptr(g_depth), ptr(g_small), ptr(loss), stream_ptr()), "a3r_align_grad")
-        g = dict(pw_poses=g_pw, depth=g_depth, im_poses=g_small[:, 0:7], im_focals=g_small[:, 7], im_pp=g_small[:, 8:10],
+            check(self.lib.a3r_align_grad_epoch(self.handle, int(epoch), ptr(g_pw), ptr(g_depth), ptr(g_small), ptr(loss),
+                                                stream_ptr()), "a3r_align_grad")
+        g_f = g_small[:, 7].sum().reshape(1) if self.shared_focal else g_small[:, 7]
+        g = dict(pw_poses=g_pw, depth=g_depth, im_poses=g_small[:, 0:7], im_focals=g_f, im_pp=g_small[:, 8:10],
                  shifts=g_small[:, 10])
         return float(loss.item()), {k: g[k] for k in self.trainable()}
 
-    def step(self, lr):
+    def step(self, lr, epoch=None):
         with torch.cuda.device(self.device):
-            check(self.lib.a3r_align_step(self.handle, float(lr), stream_ptr()), "a3r_align_step")
+            if epoch is None:
+                check(self.lib.a3r_align_step(self.handle, float(lr), stream_ptr()), "a3r_align_step")
+            else:
+                check(self.lib.a3r_align_step_epoch(self.handle, float(lr), int(epoch), stream_ptr()), "a3r_align_step")
+
+    @property
+    def flow_dropped(self):
+        """True once the flow term was dropped because its loss exceeded flow_loss_thre (self.flow_loss_flag)."""
+        if self.flow is None:
+            return False
+        st = np.zeros(5, np.float32)
+        check(self.lib.a3r_align_flow_state(self.handle, st.ctypes.data_as(C.c_void_p)))
+        return bool(st[4] != 0)
 
     def run(self, niter, lr, schedule="cosine", lr_min=1e-6, first_iter=0, total_iters=None):
         """global_alignment_loop (base_opt.py:424-447) without per-iteration host syncs; returns the losses."""
         total = total_iters or niter
         start = self.steps_done
         for it in range(first_iter, first_iter + niter):
-            t = it / total
-            if schedule == "cosine":
-                cur = cosine_schedule(t, lr, lr_min)
-            elif schedule == "linear":
-                cur = linear_schedule(t, lr, lr_min)
-            else:
-                raise ValueError(f"bad lr schedule={schedule!r}")
-            self.step(cur)
+            self.step(schedule_lr(schedule, it / total, lr, lr_min), epoch=it)
         return self.loss_history[start:start + niter].cpu().numpy().astype(np.float64)
 
     def pose_matrices(self):

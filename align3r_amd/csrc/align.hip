@@ -39,6 +39,19 @@ struct AlignDev {
     float *edge_xf, *img_xf, *partE, *partN, *gE, *gN, *lossE;
     const int *inc_ptr, *inc, *slot_of, *imw, *imarea;
     float* loss_history;
+    // cloud_opt_flow extras (a3r_align_set_flow); all zero / null for the plain cloud_opt aligner
+    int shared_focal;
+    float tsw, trans_w;               // temporal smoothing weight, translation weight (optimizer.py:516-519,559-572)
+    float flow_w, flow_thre, pxl_thre;
+    int flow_on;                      // the ego-flow term takes part in THIS launch (set by the host per iteration)
+    int fH, fW;
+    const float *flow_ij, *flow_ji;   // [E, 2, P]
+    const unsigned char* dyn;         // [N, P] 1 = dynamic pixel (excluded)
+    const int* other;                 // [2E] target image of incidence slot k
+    float *gflow;                     // [2, N, P, 3] unscaled d(sum loss)/d(world point) per direction
+    float *partF, *sumF;              // [2E, nchunks, 20], [2E, 20]
+    float *flow_state;                // [8]: c0, c1, flow_loss, dropped_now, dropped_sticky
+    float *lossN;                     // [N] temporal-smoothing loss of the pair (n, n+1)
 };
 
 struct AdamArgs {
@@ -125,7 +138,7 @@ __device__ void build_transforms(const AlignDev& d, float* sh /* >= TPB floats *
             for (int k = 0; k < 3; k++) o[r * 4 + k] = R[r * 3 + k];
             o[r * 4 + 3] = signed_expm1f(p[4 + r]);
         }
-        o[12] = expf(d.im_focals[n] / d.focal_break);
+        o[12] = expf(d.im_focals[d.shared_focal ? 0 : n] / d.focal_break);
         o[13] = d.pp0[n * 2 + 0] + 10.f * d.im_pp[n * 2 + 0];
         o[14] = d.pp0[n * 2 + 1] + 10.f * d.im_pp[n * 2 + 1];
         o[15] = d.mono ? d.shifts[n] : 0.f;
@@ -261,6 +274,18 @@ __global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
         for (int r = 0; r < 3; r++) {
             proj[i][r] = R[r * 3] * rel[0] + R[r * 3 + 1] * rel[1] + R[r * 3 + 2] * rel[2] + T[r];
             gp[i][r] = 0.f;
+        }
+    }
+    if (MODE != 0 && d.flow_on) {
+        // ego-flow term (align_flow_kernel): its gradient w.r.t. this pixel's world point, scaled by weight / sum(mask)
+        const float c0 = d.flow_state[0], c1 = d.flow_state[1];
+        const size_t NP3 = (size_t)d.N * P * 3;
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            if (!valid[i]) continue;
+            const float* gf = d.gflow + ((size_t)n * P + pix0 + i * PSTEP) * 3;
+#pragma unroll
+            for (int r = 0; r < 3; r++) gp[i][r] = c0 * gf[r] + c1 * gf[NP3 + r];
         }
     }
 
@@ -418,6 +443,197 @@ __global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------- ego-flow term (cloud_opt_flow)
+// optimizer.py:521-541 with DepthBasedWarping (goem_opt.py:195-236) and smooth_L1_loss_fn (optimizer.py:18-24).
+// Image-major like the main kernel: the block's image is the SOURCE of every incident (edge, side); side 0 compares
+// the ego-flow ei -> ej with flow_ij, side 1 the ego-flow ej -> ei with flow_ji.  Everything is UNSCALED by
+// weight / sum(mask) (known only after the whole pass): per pixel the gradient w.r.t. the world point, per
+// (edge, side) the loss sums and the gradient sums of the TARGET camera.
+constexpr int NF = 17, NFP = 20;    // per-slot sums: S, C, d/df_t, d/dcx_t, d/dcy_t, sum gY[3], sum v (x) gY [9]
+
+__global__ __launch_bounds__(TPB) void align_flow_kernel(AlignDev d, const int* __restrict__ inc_ptr, const int* __restrict__ inc,
+                                                          const int* __restrict__ other, const float* __restrict__ img_xf) {
+    __shared__ float red[2][EB][16][NFP];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = d.P, W = d.fW;
+    const float* ix = img_xf + n * 16;
+    float Rs[9], Ts[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { Rs[r * 3] = ix[r * 4]; Rs[r * 3 + 1] = ix[r * 4 + 1]; Rs[r * 3 + 2] = ix[r * 4 + 2]; Ts[r] = ix[r * 4 + 3]; }
+    const float fs = ix[12], cxs = ix[13], cys = ix[14];
+    float px[PXT], py[PXT], dpv[PXT], Pw[PXT][3], g0[PXT][3], g1[PXT][3];
+    bool ok[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const int p = chunk * CHUNK + i * TPB + tid;
+        const bool in = p < P;
+        ok[i] = in && d.dyn[(size_t)n * P + p] == 0;          // mask = ~dynamic_mask of the source image
+        const float dp = (in ? expf(d.depth[(size_t)n * P + p]) : 1.f) + 1e-6f;   // 1 / disp
+        dpv[i] = dp;
+        const int y = p / W, x = p - y * W;
+        px[i] = (float)x; py[i] = (float)y;
+        const float X0 = dp * (px[i] - cxs) / fs, X1 = dp * (py[i] - cys) / fs, X2 = dp;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Pw[i][r] = Rs[r * 3] * X0 + Rs[r * 3 + 1] * X1 + Rs[r * 3 + 2] * X2 + Ts[r];
+            g0[i][r] = 0.f; g1[i][r] = 0.f;
+        }
+    }
+    const int kbeg = inc_ptr[n], kend = inc_ptr[n + 1];
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += EB) {
+#pragma unroll 1
+        for (int kb = 0; kb < EB; kb++) {
+            const int k = k0 + kb;
+            if (k >= kend) break;
+            const int code = inc[k], e = code >> 1, side = code & 1, t = other[k];
+            const float* tx = img_xf + t * 16;
+            const float r00 = tx[0], r01 = tx[1], r02 = tx[2], t0 = tx[3];
+            const float r10 = tx[4], r11 = tx[5], r12 = tx[6], t1 = tx[7];
+            const float r20 = tx[8], r21 = tx[9], r22 = tx[10], t2 = tx[11];
+            const float ft = tx[12], cxt = tx[13], cyt = tx[14];
+            const float* fl = (side ? d.flow_ji : d.flow_ij) + (size_t)e * 2 * P;
+            float acc[NF];
+#pragma unroll
+            for (int j = 0; j < NF; j++) acc[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < PXT; i++) {
+                const int p = chunk * CHUNK + i * TPB + tid;
+                const float gt0 = ok[i] ? fl[p] : 0.f, gt1 = ok[i] ? fl[P + p] : 0.f;
+                const float v0 = Pw[i][0] - t0, v1 = Pw[i][1] - t1, v2 = Pw[i][2] - t2;
+                const float Y0 = r00 * v0 + r10 * v1 + r20 * v2;        // Y = R_t^T v
+                const float Y1 = r01 * v0 + r11 * v1 + r21 * v2;
+                const float Y2 = r02 * v0 + r12 * v1 + r22 * v2;
+                const float qx = ft * Y0 + cxt * Y2, qy = ft * Y1 + cyt * Y2;
+                // the reference normalises disp*K*Y by (disp*z + 1e-6), i.e. K*Y by (z + 1e-6 / disp)
+                const float den = Y2 + 1e-6f * dpv[i];
+                const float iz = 1.f / den;
+                const float e0 = qx * iz - px[i], e1 = qy * iz - py[i];
+                float gn0 = 0.f, gn1 = 0.f;
+                if (ok[i]) {
+                    const float d0 = e0 - gt0, a0 = fabsf(d0), l0 = a0 < 1.f ? 0.5f * d0 * d0 : a0 - 0.5f;
+                    const float d1 = e1 - gt1, a1 = fabsf(d1), l1 = a1 < 1.f ? 0.5f * d1 * d1 : a1 - 0.5f;
+                    if (l0 < d.pxl_thre) { acc[0] += l0; acc[1] += 1.f; gn0 = a0 < 1.f ? d0 : (d0 > 0.f ? 1.f : -1.f); }
+                    if (l1 < d.pxl_thre) { acc[0] += l1; acc[1] += 1.f; gn1 = a1 < 1.f ? d1 : (d1 > 0.f ? 1.f : -1.f); }
+                }
+                const float gq0 = gn0 * iz, gq1 = gn1 * iz, gq2 = -(gn0 * qx + gn1 * qy) * iz * iz;
+                const float gY0 = ft * gq0, gY1 = ft * gq1, gY2 = cxt * gq0 + cyt * gq1 + gq2;
+                acc[2] += gq0 * Y0 + gq1 * Y1;
+                acc[3] += gq0 * Y2;
+                acc[4] += gq1 * Y2;
+                acc[5] += gY0; acc[6] += gY1; acc[7] += gY2;
+                acc[8] += v0 * gY0; acc[9] += v0 * gY1; acc[10] += v0 * gY2;
+                acc[11] += v1 * gY0; acc[12] += v1 * gY1; acc[13] += v1 * gY2;
+                acc[14] += v2 * gY0; acc[15] += v2 * gY1; acc[16] += v2 * gY2;
+                const float gw0 = r00 * gY0 + r01 * gY1 + r02 * gY2;     // gPw = R_t gY
+                const float gw1 = r10 * gY0 + r11 * gY1 + r12 * gY2;
+                const float gw2 = r20 * gY0 + r21 * gY1 + r22 * gY2;
+                if (side) { g1[i][0] += gw0; g1[i][1] += gw1; g1[i][2] += gw2; }
+                else { g0[i][0] += gw0; g0[i][1] += gw1; g0[i][2] += gw2; }
+            }
+#pragma unroll
+            for (int j = 0; j < NF; j++) {
+                const float s = dpp_row_sum16(acc[j]);
+                if ((lane & 15) == 0) red[buf][kb][wave * 4 + (lane >> 4)][j] = s;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < EB * NFP; idx += TPB) {
+            const int kb = idx / NFP, j = idx - kb * NFP, k = k0 + kb;
+            if (k < kend && j < NF) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) s += red[buf][kb][r][j];
+                d.partF[((size_t)k * d.nchunks + chunk) * NFP + j] = s;
+            }
+        }
+        buf ^= 1;
+    }
+    const size_t NP3 = (size_t)d.N * P * 3;
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const int p = chunk * CHUNK + i * TPB + tid;
+        if (p >= P) continue;
+        float* o = d.gflow + ((size_t)n * P + p) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { o[r] = g0[i][r]; o[NP3 + r] = g1[i][r]; }
+    }
+}
+
+// grid 2E x 64 threads: fixed-order sum of the chunk partials of one incidence slot
+__global__ __launch_bounds__(64) void align_flow_reduce_kernel(AlignDev d) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (lane >= NFP) return;
+    float s = 0.f;
+    for (int c = 0; c < d.nchunks; c++) s += d.partF[((size_t)k * d.nchunks + c) * NFP + lane];
+    d.sumF[k * NFP + lane] = lane < NF ? s : 0.f;
+}
+
+// one block: the two normalisers, the loss value, the drop decision (optimizer.py:536-540)
+__global__ __launch_bounds__(TPB) void align_flow_decide_kernel(AlignDev d, const int* __restrict__ inc) {
+    __shared__ double sh[4][4];
+    const int tid = threadIdx.x;
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = tid; k < 2 * d.E; k += TPB) {
+        const int dir = inc[k] & 1;
+        acc[dir * 2] += (double)d.sumF[k * NFP];
+        acc[dir * 2 + 1] += (double)d.sumF[k * NFP + 1];
+    }
+    for (int j = 0; j < 4; j++) {
+        double v = acc[j];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) sh[j][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t[4];
+        for (int j = 0; j < 4; j++) t[j] = sh[j][0] + sh[j][1] + sh[j][2] + sh[j][3];
+        const float loss = (float)(t[0] / t[1] + t[2] / t[3]);
+        const bool dropped = loss > d.flow_thre && d.flow_thre > 0.f;
+        d.flow_state[0] = dropped ? 0.f : (float)(d.flow_w / t[1]);
+        d.flow_state[1] = dropped ? 0.f : (float)(d.flow_w / t[3]);
+        d.flow_state[2] = loss;
+        d.flow_state[3] = dropped ? 1.f : 0.f;
+        if (dropped) d.flow_state[4] = 1.f;          // sticky, like self.flow_loss_flag
+    }
+}
+
+// relative_pose_loss between images a and b = a + 1 (optimizer.py:559-572): loss, and gradient w.r.t. rotation /
+// translation of `which` (0: a, 1: b) accumulated into GR[9], GT[3].
+__device__ double temporal_pair(const float* Ra, const float* Ta, const float* Rb, const float* Tb, float tw, int which,
+                                double* GR, double* GT) {
+    double M[9], a = 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)Ra[k * 3 + i] * Rb[k * 3 + j];
+            M[i * 3 + j] = s - (i == j);
+            a += M[i * 3 + j] * M[i * 3 + j];
+        }
+    a = sqrt(a);
+    double dv[3], u[3], un = 0;
+    for (int k = 0; k < 3; k++) dv[k] = (double)Tb[k] - Ta[k];
+    for (int i = 0; i < 3; i++) { u[i] = Ra[i] * dv[0] + Ra[3 + i] * dv[1] + Ra[6 + i] * dv[2]; un += u[i] * u[i]; }
+    un = sqrt(un);
+    if (a > 0)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += which ? (double)Ra[i * 3 + k] * M[k * 3 + j] / a : (double)Rb[i * 3 + k] * M[j * 3 + k] / a;
+                GR[i * 3 + j] += s;
+            }
+    if (un > 0) {
+        double gu[3], Rg[3];
+        for (int i = 0; i < 3; i++) gu[i] = tw * u[i] / un;
+        for (int i = 0; i < 3; i++) Rg[i] = Ra[i * 3] * gu[0] + Ra[i * 3 + 1] * gu[1] + Ra[i * 3 + 2] * gu[2];
+        for (int i = 0; i < 3; i++) {
+            GT[i] += which ? Rg[i] : -Rg[i];
+            if (!which) for (int j = 0; j < 3; j++) GR[i * 3 + j] += dv[i] * gu[j];
+        }
+    }
+    return a + tw * un;
+}
+
 // ------------------------------------------------------------------------------------------- finalize A
 // grid E + N blocks of 64 threads: fixed-order sum of the chunk partials, chain rule for the small parameters.
 __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int loss_only) {
@@ -472,8 +688,8 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
                 g[7] = (float)(dLds * sc);   // S_e * s_e; the mean coupling is applied in finalize B
             }
         }
-    } else if (!loss_only) {
-        const int n = b - d.E;
+    } else {
+        const int n = b - d.E;   // (in loss-only launches the partial sums are stale: only lossN is consumed)
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
         const int q = lane & 3;
         const f32x4* pn = reinterpret_cast<const f32x4*>(d.partN + (size_t)n * d.nchunks * 16);
@@ -492,6 +708,42 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
             const float* p = d.im_poses + n * 7;
             float R[9], qn[4], nrm;
             quat_to_R(p, R, qn, &nrm);
+            if (d.flow_on) {
+                // image n as the TARGET camera of the ego-flow of the opposite side of each incident edge
+                const float fn = d.img_xf[n * 16 + 12];
+                for (int k = d.inc_ptr[n]; k < d.inc_ptr[n + 1]; k++) {
+                    const int code = d.inc[k], opp = d.slot_of[(code >> 1) * 2 + (1 - (code & 1))];
+                    const double c = d.flow_state[1 - (code & 1)];
+                    const float* F = d.sumF + opp * NFP;
+                    for (int j = 0; j < 9; j++) s[j] += c * F[8 + j];                       // dL/dR_t = v (x) gY
+                    for (int i = 0; i < 3; i++)
+                        s[9 + i] -= c * ((double)R[i * 3] * F[5] + (double)R[i * 3 + 1] * F[6] + (double)R[i * 3 + 2] * F[7]);
+                    s[12] += c * F[2] * fn / d.focal_break;
+                    s[13] += 10.0 * c * F[3];
+                    s[14] += 10.0 * c * F[4];
+                }
+            }
+            if (d.tsw > 0.f) {
+                float Tn[3], Ro[9], To[3];
+                for (int k = 0; k < 3; k++) Tn[k] = signed_expm1f(p[4 + k]);
+                double GR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, GT[3] = {0, 0, 0};
+                if (n + 1 < d.N) {
+                    const float* po = d.im_poses + (n + 1) * 7;
+                    quat_to_R(po, Ro, nullptr, nullptr);
+                    for (int k = 0; k < 3; k++) To[k] = signed_expm1f(po[4 + k]);
+                    d.lossN[n] = (float)(d.tsw * temporal_pair(R, Tn, Ro, To, d.trans_w, 0, GR, GT));
+                } else {
+                    d.lossN[n] = 0.f;
+                }
+                if (n > 0) {
+                    const float* po = d.im_poses + (n - 1) * 7;
+                    quat_to_R(po, Ro, nullptr, nullptr);
+                    for (int k = 0; k < 3; k++) To[k] = signed_expm1f(po[4 + k]);
+                    temporal_pair(Ro, To, R, Tn, d.trans_w, 1, GR, GT);
+                }
+                for (int j = 0; j < 9; j++) s[j] += d.tsw * GR[j];
+                for (int j = 0; j < 3; j++) s[9 + j] += d.tsw * GT[j];
+            }
             double gq[4];
             quat_backward(qn, nrm, s, gq);
             float* g = d.gN + n * 16;
@@ -520,9 +772,11 @@ __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamA
     for (int o = 32; o > 0; o >>= 1) { lsum += __shfl_xor(lsum, o); ssum += __shfl_xor(ssum, o); }
     if ((tid & 63) == 0) { shd[0][tid >> 6] = lsum; shd[1][tid >> 6] = ssum; }
     __syncthreads();
-    const double loss = shd[0][0] + shd[0][1] + shd[0][2] + shd[0][3];
+    double loss = shd[0][0] + shd[0][1] + shd[0][2] + shd[0][3];
     const double sumSs = shd[1][0] + shd[1][1] + shd[1][2] + shd[1][3];
     if (tid == 0) {
+        if (d.tsw > 0.f) for (int n = 0; n + 1 < d.N; n++) loss += (double)d.lossN[n];
+        if (d.flow_on && d.flow_state[3] == 0.f) loss += (double)d.flow_w * d.flow_state[2];
         if (MODE == 2) d.loss_history[ad.step] = (float)loss;
         else *loss_out = (float)loss;
     }
@@ -545,7 +799,7 @@ __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamA
         if (MODE == 1) { g_small[i] = g; continue; }
         float* target = nullptr;
         if (j < 7) { if (d.train_poses) target = d.im_poses + n * 7 + j; }
-        else if (j == 7) { if (d.train_focals) target = d.im_focals + n; }
+        else if (j == 7) { if (d.train_focals && !d.shared_focal) target = d.im_focals + n; }
         else if (j < 10) { if (d.train_pp) target = d.im_pp + n * 2 + (j - 8); }
         else if (j == 10) { if (d.mono) target = d.shifts + n; }
         if (target) {
@@ -553,6 +807,14 @@ __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamA
             adam_update(p, g, m, v, ad);
             *target = p; d.adam_small[i] = m; d.adam_small[d.N * 16 + i] = v;
         }
+    }
+    if (MODE == 2 && d.shared_focal && d.train_focals && tid == 0) {
+        // one focal parameter shared by every image (optimizer.py:56-58): its gradient is the sum over images
+        double g = 0.0;
+        for (int n = 0; n < d.N; n++) g += (double)d.gN[n * 16 + 7];
+        float m = d.adam_small[7], v = d.adam_small[d.N * 16 + 7], p = d.im_focals[0];
+        adam_update(p, (float)g, m, v, ad);
+        d.im_focals[0] = p; d.adam_small[7] = m; d.adam_small[d.N * 16 + 7] = v;
     }
     if (MODE == 2) {
         __syncthreads();          // parameter stores above are visible to the whole workgroup
@@ -577,6 +839,8 @@ struct a3r_align_s {
     int steps;
     int loss_capacity;
     bool dirty;      // parameters changed by the caller since the transforms were last built
+    std::vector<int> ei, ej, inc;     // host copies of the graph (for a3r_align_set_flow)
+    int flow_start_iter = 0;
 };
 
 static void refresh_if_dirty(a3r_align_s* a, hipStream_t st) {
@@ -677,6 +941,9 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     d.loss_history = s->loss_history;
     a->use_mono = s->use_mono != 0; a->dist_l2 = s->dist_l2 != 0; a->steps = 0; a->loss_capacity = s->loss_capacity;
     a->dirty = true;
+    a->ei.assign(s->ei_host, s->ei_host + s->E);
+    a->ej.assign(s->ej_host, s->ej_host + s->E);
+    a->inc = inc;
     *out = a;
     return A3R_OK;
 }
@@ -708,7 +975,70 @@ static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, hipS
 #undef A3R_ALIGN_LAUNCH
 }
 
-extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {
+// ---- cloud_opt_flow extras -------------------------------------------------------------------------------------
+static size_t flow_ws_layout(int E, int N, int P, size_t* off /*[6]*/) {
+    const int nch = (P + CHUNK - 1) / CHUNK;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    off[0] = take((size_t)2 * N * P * 3 * 4);          // gflow
+    off[1] = take((size_t)2 * E * nch * NFP * 4);      // partF
+    off[2] = take((size_t)2 * E * NFP * 4);            // sumF
+    off[3] = take(8 * 4);                              // flow_state
+    off[4] = take((size_t)N * 4);                      // lossN
+    off[5] = take((size_t)2 * E * 4);                  // other
+    return o;
+}
+
+extern "C" size_t a3r_align_flow_workspace_bytes(int E, int N, int P) {
+    size_t off[6];
+    return flow_ws_layout(E, N, P, off);
+}
+
+extern "C" int a3r_align_set_flow(a3r_align_t a, const a3r_align_flow_desc* f, void* stream) {
+    A3R_CHECK_ARG(a && f, "a3r_align_set_flow: null argument");
+    A3R_CHECK_ARG(!a->use_mono, "a3r_align_set_flow: the flow variant has no mono-depth parameterisation (cloud_opt_flow/optimizer.py:52)");
+    AlignDev& d = a->d;
+    size_t off[6];
+    const size_t need = flow_ws_layout(d.E, d.N, d.P, off);
+    A3R_CHECK_ARG(f->workspace && f->workspace_bytes >= need, "a3r_align_set_flow: workspace too small (%zu < %zu)", f->workspace_bytes, need);
+    A3R_CHECK_ARG(f->temporal_smoothing_weight >= 0.f && f->flow_loss_weight >= 0.f, "a3r_align_set_flow: negative weight");
+    if (f->flow_loss_weight > 0.f) {
+        A3R_CHECK_ARG(f->flow_ij && f->flow_ji && f->dynamic_mask, "a3r_align_set_flow: flow_loss_weight > 0 needs flow_ij, flow_ji and dynamic_mask");
+        A3R_CHECK_ARG(f->H > 0 && f->W > 0 && f->H * f->W == d.P, "a3r_align_set_flow: H*W must equal P (all images of one shape)");
+    }
+    char* ws = (char*)f->workspace;
+    hipStream_t st = as_stream(stream);
+    std::vector<int> other(2 * d.E);
+    for (int k = 0; k < 2 * d.E; k++) {
+        const int e = a->inc[k] >> 1, side = a->inc[k] & 1;
+        other[k] = side ? a->ei[e] : a->ej[e];
+    }
+    A3R_HIP(hipMemcpyAsync(ws + off[5], other.data(), other.size() * 4, hipMemcpyHostToDevice, st));
+    A3R_HIP(hipMemsetAsync(ws + off[3], 0, 32, st));
+    A3R_HIP(hipMemsetAsync(ws + off[4], 0, (size_t)d.N * 4, st));
+    A3R_HIP(hipStreamSynchronize(st));
+    d.shared_focal = f->shared_focal; d.tsw = f->temporal_smoothing_weight; d.trans_w = f->translation_weight;
+    d.flow_w = f->flow_loss_weight; d.flow_thre = f->flow_loss_thre; d.pxl_thre = f->pxl_thre;
+    d.fH = f->H; d.fW = f->W; d.flow_ij = f->flow_ij; d.flow_ji = f->flow_ji; d.dyn = f->dynamic_mask;
+    d.gflow = (float*)(ws + off[0]); d.partF = (float*)(ws + off[1]); d.sumF = (float*)(ws + off[2]);
+    d.flow_state = (float*)(ws + off[3]); d.lossN = (float*)(ws + off[4]); d.other = (const int*)(ws + off[5]);
+    a->flow_start_iter = f->flow_start_iter;
+    a->dirty = true;
+    return A3R_OK;
+}
+
+// the ego-flow pass of one iteration (before the main kernel): unscaled sums, then the normalisers / drop decision
+static void launch_flow(a3r_align_s* a, int epoch, hipStream_t st) {
+    AlignDev& d = a->d;
+    d.flow_on = (d.flow_w > 0.f && epoch >= a->flow_start_iter) ? 1 : 0;
+    if (!d.flow_on) return;
+    ProfScope prof(PK_ALIGN_SMALL, 0.0, st);
+    hipLaunchKernelGGL(align_flow_kernel, dim3(d.nchunks, d.N), dim3(TPB), 0, st, d, d.inc_ptr, d.inc, d.other, d.img_xf);
+    hipLaunchKernelGGL(align_flow_reduce_kernel, dim3(2 * d.E), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(align_flow_decide_kernel, dim3(1), dim3(TPB), 0, st, d, d.inc);
+}
+
+extern "C" int a3r_align_step_epoch(a3r_align_t a, float lr, int epoch, void* stream) {
     A3R_CHECK_ARG(a, "a3r_align_step: null handle");
     A3R_CHECK_ARG(a->steps < a->loss_capacity, "a3r_align_step: loss_history full (%d)", a->loss_capacity);
     hipStream_t st = as_stream(stream);
@@ -719,6 +1049,7 @@ extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {
     ad.bc2_sqrt = (float)sqrt(1.0 - pow((double)ADAM_B2, t));
     ad.step = a->steps;
     refresh_if_dirty(a, st);
+    launch_flow(a, epoch, st);
     launch_main<2>(a, ad, nullptr, st);
     {
         ProfScope prof(PK_ALIGN_SMALL, 0.0, st);
@@ -730,28 +1061,46 @@ extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {
     return A3R_OK;
 }
 
+extern "C" int a3r_align_step(a3r_align_t a, float lr, void* stream) {
+    return a3r_align_step_epoch(a, lr, a ? a->steps : 0, stream);     // epoch = iteration index of this handle
+}
+
 extern "C" int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream) {
     A3R_CHECK_ARG(a && loss_dev, "a3r_align_loss: null argument");
     hipStream_t st = as_stream(stream);
     AdamArgs ad = {};
     refresh_if_dirty(a, st);
+    launch_flow(a, 1 << 30, st);                                       // net() defaults to epoch=9999: flow term active
     launch_main<0>(a, ad, nullptr, st);
-    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E), dim3(64), 0, st, a->d, 1);
+    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 1);
     hipLaunchKernelGGL((align_finalize_b_kernel<0>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, loss_dev);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_align_grad_epoch(a3r_align_t a, int epoch, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,
+                                    void* stream) {
+    A3R_CHECK_ARG(a && g_pw_poses && g_depth && g_small && loss_dev, "a3r_align_grad: null argument");
+    hipStream_t st = as_stream(stream);
+    AdamArgs ad = {};
+    refresh_if_dirty(a, st);
+    launch_flow(a, epoch, st);
+    launch_main<1>(a, ad, g_depth, st);
+    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
+    hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, g_pw_poses, g_small, loss_dev);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
 
 extern "C" int a3r_align_grad(a3r_align_t a, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,
                               void* stream) {
-    A3R_CHECK_ARG(a && g_pw_poses && g_depth && g_small && loss_dev, "a3r_align_grad: null argument");
-    hipStream_t st = as_stream(stream);
-    AdamArgs ad = {};
-    refresh_if_dirty(a, st);
-    launch_main<1>(a, ad, g_depth, st);
-    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
-    hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, g_pw_poses, g_small, loss_dev);
-    A3R_LAUNCH_CHECK();
+    return a3r_align_grad_epoch(a, 1 << 30, g_pw_poses, g_depth, g_small, loss_dev, stream);
+}
+
+extern "C" int a3r_align_flow_state(a3r_align_t a, float* state_host5) {
+    A3R_CHECK_ARG(a && state_host5, "a3r_align_flow_state: null argument");
+    A3R_CHECK_ARG(a->d.flow_state, "a3r_align_flow_state: a3r_align_set_flow has not been called");
+    A3R_HIP(hipMemcpy(state_host5, a->d.flow_state, 5 * sizeof(float), hipMemcpyDeviceToHost));
     return A3R_OK;
 }
 

@@ -234,6 +234,34 @@ int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream);
 /* Gradients of the current state without updating (for the parity tests):
  * g_pw_poses [E,8], g_depth [N,P], g_small [N,16] (layout of adam_small), loss_dev [1]. */
 int a3r_align_grad(a3r_align_t a, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev, void* stream);
+/* cloud_opt_flow variant (dust3r/cloud_opt_flow/optimizer.py:36-116,500-572): shared focal, temporal smoothing of
+ * consecutive image poses (relative_pose_loss), ego-flow smooth-L1 term against precomputed optical flow (the RAFT
+ * fields and the dynamic masks are INPUTS).  Call once after a3r_align_create (not with use_mono).  With shared_focal
+ * im_focals has one element and the Adam moments of the focal live in slot [0][7] of adam_small. */
+typedef struct {
+    int shared_focal;
+    float temporal_smoothing_weight;   /* 0 disables */
+    float translation_weight;
+    float flow_loss_weight;            /* 0 disables the ego-flow term */
+    float flow_loss_thre;              /* > 0: the term is dropped in an iteration whose flow loss exceeds it (optimizer.py:538) */
+    float pxl_thre;                    /* per-element threshold of smooth_L1_loss_fn (optimizer.py:18-24) */
+    int flow_start_iter;               /* first epoch e with e >= num_total_iter * flow_loss_start_epoch */
+    int H, W;                          /* image shape, H*W == P */
+    const float* flow_ij;              /* [E, 2, H*W] flow of image ei towards ej (x then y planes), device */
+    const float* flow_ji;              /* [E, 2, H*W] */
+    const uint8_t* dynamic_mask;       /* [N, H*W], 1 = dynamic pixel (excluded), device */
+    void* workspace;                   /* >= a3r_align_flow_workspace_bytes(E, N, P), device */
+    size_t workspace_bytes;
+} a3r_align_flow_desc;
+size_t a3r_align_flow_workspace_bytes(int E, int N, int P);
+int a3r_align_set_flow(a3r_align_t a, const a3r_align_flow_desc* f, void* stream);
+/* a3r_align_step with an explicit epoch (net(epoch=cur_iter), cloud_opt_flow/base_opt.py:571); a3r_align_step uses
+ * the handle's own iteration count. */
+int a3r_align_step_epoch(a3r_align_t a, float lr, int epoch, void* stream);
+int a3r_align_grad_epoch(a3r_align_t a, int epoch, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,
+                         void* stream);
+/* HOST out[5] = {c_ij, c_ji, last flow loss, dropped in the last evaluation, dropped ever (flow_loss_flag)}; synchronises. */
+int a3r_align_flow_state(a3r_align_t a, float* state_host5);
 int a3r_align_steps_done(a3r_align_t a);
 /* Tell the handle that the caller rewrote parameter buffers (preset_pose, init, load_state_dict ...). */
 int a3r_align_invalidate(a3r_align_t a);

@@ -132,3 +132,46 @@ def test_deterministic(Engine):
         outs.append({k: host(v).copy() for k, v in a.params.items()})
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k      # fixed-order reductions: bitwise reproducible
+
+
+# ------------------------------------------------------------------------------------------------- cloud_opt_flow (a-14)
+from test_oracle_align import FLOW_META, FLOW_NAMES, build_flow
+
+
+@pytest.fixture(scope="module")
+def gf():
+    return np.load(os.path.join(GOLDEN, "alignflow.npz"))
+
+
+@pytest.mark.parametrize("case", FLOW_META["cases"], ids=[c["tag"] for c in FLOW_META["cases"]])
+def test_flow_variant_gradients_vs_reference(case, gf, Engine):
+    a = build_flow(case, gf, cls=Engine)
+    tag = case["tag"]
+    for et, epoch in (("on", 9999), ("off", 0)):
+        loss, gr = a.loss_grad(epoch)
+        assert abs(loss - gf[f"{tag}_loss_{et}"]) / gf[f"{tag}_loss_{et}"] < 1e-6
+        for k, v in gr.items():
+            ref = gf[f"{tag}_grad_{et}_{FLOW_NAMES[k]}"]
+            assert rel_err(host(v).reshape(ref.shape), ref) < 1e-5, (et, k)
+    if case["flow_loss_weight"] > 0 and not case["flow_dropped"]:
+        _, g_on = a.loss_grad(9999)
+        _, g_off = a.loss_grad(0)
+        for k in ("im_poses", "im_focals"):       # the flow term in isolation
+            ref = gf[f"{tag}_grad_on_{FLOW_NAMES[k]}"].astype(np.float64) - gf[f"{tag}_grad_off_{FLOW_NAMES[k]}"]
+            mine = (host(g_on[k]).astype(np.float64) - host(g_off[k])).reshape(ref.shape)
+            assert rel_err(mine, ref) < 1e-3, k
+
+
+@pytest.mark.parametrize("case", FLOW_META["cases"], ids=[c["tag"] for c in FLOW_META["cases"]])
+def test_flow_variant_trajectory_vs_reference(case, gf, Engine):
+    a = build_flow(case, gf, cls=Engine)
+    tag = case["tag"]
+    losses, done = [], 0
+    for k in (1, 5, 10, 50):
+        losses += list(a.run(k - done, case["lr"], case["schedule"], case["lr_min"], first_iter=done, total_iters=case["niter"]))
+        done = k
+        for kk in a.trainable():
+            ref = gf[f"{tag}_k{k}_{FLOW_NAMES[kk]}"]
+            assert rel_err(host(a.params[kk]).reshape(ref.shape), ref) < 1e-4, (k, kk)
+    assert rel_err(np.asarray(losses), gf[tag + "_losses"]) < 1e-5
+    assert a.flow_dropped == case["flow_dropped"]
