@@ -1,0 +1,128 @@
+"""cloud_opt_flow.PointCloudOptimizer behind the reference's API (dust3r/cloud_opt_flow/optimizer.py:30-572).
+
+Same keywords and parameterisation as the reference: log-depth maps (no mono prior), optional shared focal,
+temporal smoothing of consecutive camera poses, ego-flow smooth-L1 loss against optical flow with dynamic masks,
+`flow_loss_start_epoch` / `flow_loss_thre` gating, cosine / linear / cycleN schedules, lr_min default 1e-3
+(cloud_opt_flow/base_opt.py:513).  The loop runs in liba3r (a3r_align_step_epoch).
+
+The optical-flow fields are INPUTS of the path: the reference computes them with RAFT inside the constructor
+(optimizer.py:118-154; SURVEY row N4, not built), here they are passed as ``flow=(flow_ij, flow_ji)``
+([E,2,H,W] each); the dynamic masks come from ``view['dynamic_mask']`` exactly as in the reference
+(cloud_opt_flow/base_opt.py:129-138).  depth_regularize_weight > 0, use_self_mask and sam2_mask_refine raise.
+"""
+from __future__ import annotations
+
+import torch
+
+from ...aligner import AlignEngine
+from ..cloud_opt.optimizer import PointCloudOptimizer as _Base
+
+
+class PointCloudOptimizer(_Base):
+    def __init__(self, view1, view2, pred1, pred2, optimize_pp=False, focal_break=20, shared_focal=False,
+                 flow_loss_fn='smooth_l1', flow_loss_weight=0.0, depth_regularize_weight=0.0, num_total_iter=300,
+                 temporal_smoothing_weight=0, translation_weight=0.1, flow_loss_start_epoch=0.15, flow_loss_thre=50,
+                 sintel_ckpt=False, use_self_mask=False, pxl_thre=50, sam2_mask_refine=False, motion_mask_thre=0.35,
+                 flow=None, thr_for_init_conf=False, empty_cache=False, **kwargs):
+        if depth_regularize_weight > 0:
+            raise NotImplementedError('depth_regularize_weight > 0 (depth_regularization_si_weighted) is not built')
+        if flow_loss_fn != 'smooth_l1':
+            raise NotImplementedError("only flow_loss_fn='smooth_l1' (the reference's 'mse' branch is broken: optimizer.py:101)")
+        if sam2_mask_refine:
+            raise NotImplementedError('sam2_mask_refine: SAM-2 is out of scope (SURVEY section 2)')
+        super().__init__(view1, view2, pred1, pred2, False, [], optimize_pp=optimize_pp, focal_break=focal_break, **kwargs)
+        self.shared_focal = bool(shared_focal)
+        self.num_total_iter = num_total_iter
+        self.temporal_smoothing_weight = temporal_smoothing_weight
+        self.translation_weight = translation_weight
+        self.flow_loss_weight = flow_loss_weight
+        self.flow_loss_start_epoch = flow_loss_start_epoch
+        self.flow_loss_thre = flow_loss_thre
+        self.pxl_thre = pxl_thre
+        self.thr_for_init_conf = thr_for_init_conf
+        self.init_conf_maps = [c.clone() for c in self.im_conf]
+        if self.shared_focal:
+            self._init['im_focals'] = self._init['im_focals'][:1]
+        self.dynamic_masks = None
+        if 'dynamic_mask' in view1 and 'dynamic_mask' in view2:          # cloud_opt_flow/base_opt.py:129-138
+            masks = [torch.zeros(hw, dtype=torch.bool) for hw in self.imshapes]
+            for v, (i, j) in enumerate(self.edges):
+                masks[i] = torch.as_tensor(view1['dynamic_mask'][v]).bool()
+                masks[j] = torch.as_tensor(view2['dynamic_mask'][v]).bool()
+            self.dynamic_masks = masks
+        self._flow = None
+        if flow_loss_weight > 0:
+            if flow is None:
+                raise NotImplementedError('flow_loss_weight > 0 needs precomputed optical flow: pass flow=(flow_ij, flow_ji) '
+                                          '[E,2,H,W]; running RAFT inside the aligner is SURVEY row N4 (not built)')
+            if use_self_mask:
+                raise NotImplementedError('use_self_mask (get_motion_mask_from_pairs) is SURVEY row N4 (not built)')
+            if self.dynamic_masks is None:
+                raise RuntimeError("flow loss needs view['dynamic_mask'] (the reference fails on torch.stack(None), optimizer.py:531)")
+            fij, fji = flow
+            self._flow = dict(flow_ij=torch.as_tensor(fij).float(), flow_ji=torch.as_tensor(fji).float(),
+                              dyn=torch.stack(self.dynamic_masks), weight=float(flow_loss_weight), thre=float(flow_loss_thre),
+                              start_epoch=float(flow_loss_start_epoch), num_total_iter=int(num_total_iter), pxl_thre=float(pxl_thre))
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('PointCloudOptimizer: this build has no CPU compute path; pass a HIP device ("cuda")')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = device
+        E, P = len(self.edges), self.max_area
+        self.engine = AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i.reshape(E, P, 3),
+                                  self._pred_j.reshape(E, P, 3), self.conf_trf(self._conf_i).reshape(E, P),
+                                  self.conf_trf(self._conf_j).reshape(E, P), self.imshapes, mono=None,
+                                  base_scale=self.base_scale, pw_break=self.pw_break, focal_break=self.focal_break,
+                                  norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device,
+                                  shared_focal=self.shared_focal, temporal_smoothing_weight=float(self.temporal_smoothing_weight),
+                                  translation_weight=float(self.translation_weight), flow=self._flow, **self._flags)
+        self.engine.set_params(**self._init)
+        self._pred_i = self._pred_j = self._conf_i = self._conf_j = None
+        return self
+
+    @property
+    def im_focals(self):
+        return self._need_engine().params['im_focals'][:, None]
+
+    def get_focals(self):
+        lf = self.im_focals
+        if self.shared_focal:
+            lf = lf[:1].expand(self.n_imgs, 1)
+        return (lf / self.focal_break).exp()
+
+    def get_masks(self):
+        src = self.init_conf_maps if self.thr_for_init_conf else self.im_conf
+        return [(conf > self.min_conf_thr) for conf in src]
+
+    @property
+    def flow_loss_flag(self):
+        return self._need_engine().flow_dropped
+
+    def forward(self, epoch=9999):
+        loss, _ = self._need_engine().loss_grad(epoch)
+        return torch.tensor(loss, device=self.device)
+
+    __call__ = forward
+
+    def preset_focal(self, known_focals, msk=None, requires_grad=False):
+        if self.shared_focal:
+            raise NotImplementedError('preset_focal with shared_focal')
+        super().preset_focal(known_focals, msk)
+
+    def compute_global_alignment(self, init=None, init_priors=None, niter_PnP=10, lr=0.01, niter=300, schedule='cosine',
+                                 lr_min=1e-3, **kw):
+        if init is not None:
+            if init in ('msp', 'mst', 'known_poses'):
+                raise NotImplementedError(f"init={init!r}: the MST / PnP initialisation is SURVEY row N1 ('next')")
+            raise ValueError(f'bad value for {init=}')
+        e = self._need_engine()
+        if niter <= 0:
+            return float('inf')
+        e.set_params(reset_optimizer=True)
+        losses = e.run(niter, lr, schedule, lr_min)
+        if self.verbose:
+            print(f'Global alignement - {niter} iterations, loss={losses[-1]:g}')
+        return float(losses[-1])

@@ -107,3 +107,37 @@ def test_preset_pose_freezes_poses(model):
     assert rel_err(got[1].numpy(), poses[1].numpy()) < 1e-6
     scene.compute_global_alignment(init=None, niter=5, lr=0.05)
     assert torch.allclose(scene.get_im_poses().cpu(), got) and rel_err(scene.get_focals().cpu().numpy().ravel(), [300.0, 310.0]) < 1e-5
+
+
+def test_cloud_opt_flow_api_vs_reference_golden(model):
+    """dust3r.cloud_opt_flow.global_aligner + compute_global_alignment (tool/pose_test.py:168-197 shape of calls) against
+    the reference's own 50-iteration trajectory (tests/golden/alignflow.npz)."""
+    import json
+    from dust3r.cloud_opt_flow import global_aligner, GlobalAlignerMode
+    g = np.load(os.path.join(GOLDEN, "alignflow.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "alignflow.json")))
+    case = meta["cases"][0]
+    tag, N, H, W, edges = case["tag"], case["N"], case["H"], case["W"], case["edges"]
+    dyn = torch.from_numpy(g[tag + "_dyn"])
+    out = dict(view1=dict(idx=[i for i, j in edges], dynamic_mask=[dyn[i] for i, j in edges]),
+               view2=dict(idx=[j for i, j in edges], dynamic_mask=[dyn[j] for i, j in edges]),
+               pred1=dict(pts3d=torch.from_numpy(g[tag + "_p1"]), conf=torch.from_numpy(g[tag + "_c1"])),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(g[tag + "_p2"]), conf=torch.from_numpy(g[tag + "_c2"])))
+    scene = global_aligner(out, "cuda", mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False, min_conf_thr=3,
+                           shared_focal=case["shared_focal"], temporal_smoothing_weight=case["temporal_smoothing_weight"],
+                           translation_weight=case["translation_weight"], flow_loss_weight=case["flow_loss_weight"],
+                           flow_loss_start_epoch=case["flow_loss_start_epoch"], flow_loss_thre=case["flow_loss_thre"],
+                           num_total_iter=case["niter"], pxl_thre=case["pxl_thre"],
+                           flow=(g[tag + "_flow_ij"], g[tag + "_flow_ji"]))
+    assert scene.get_focals().shape == (N, 1)
+    scene.engine.set_params(pw_poses=g[tag + "_init_pw_poses"], depth=g[tag + "_init_im_depthmaps"],
+                            im_poses=g[tag + "_init_im_poses"], im_focals=g[tag + "_init_im_focals"])
+    assert abs(float(scene(epoch=9999)) - g[tag + "_loss_on"]) / g[tag + "_loss_on"] < 1e-6
+    loss = scene.compute_global_alignment(init=None, niter=case["niter"], schedule=case["schedule"], lr=case["lr"], lr_min=case["lr_min"])
+    assert abs(loss - g[tag + "_losses"][-1]) / g[tag + "_losses"][-1] < 1e-5
+    assert rel_err(scene.im_poses.cpu().numpy(), g[tag + "_k50_im_poses"]) < 1e-4
+    assert rel_err(torch.stack(scene.get_depthmaps()).cpu().numpy().reshape(N, -1), np.exp(g[tag + "_k50_im_depthmaps"])) < 1e-4
+    assert rel_err(scene.get_focals().cpu().numpy()[:1], np.exp(g[tag + "_k50_im_focals"] / 20)) < 1e-4
+    assert scene.flow_loss_flag == case["flow_dropped"]
+    with pytest.raises(NotImplementedError, match="N4"):
+        global_aligner(out, "cuda", flow_loss_weight=0.01, verbose=False)
