@@ -1,0 +1,249 @@
+"""MST initialisation of the global aligner, after dust3r/cloud_opt/init_im_poses.py:69-252.
+
+PARITY UNPINNED: the reference builds this step on third-party solvers that are not available here and whose
+results it never pins -- roma.rigid_points_registration (SVD Procrustes, :415-418) and cv2.solvePnPRansac with
+SQPNP (:442-482, stochastic).  This module restates the published algorithms (weighted Umeyama; a linear PnP with
+known intrinsics followed by an orthogonal Procrustes step and two IRLS rounds instead of RANSAC) and is validated
+by what it is for: the alignment loss after initialisation and the recovered geometry on synthetic scenes
+(tests/test_gpu_api.py).  The order of operations, the edge scores (commons.py:20-25), the spanning tree
+(scipy.sparse.csgraph), the Weiszfeld focal (post_process.py:36-60) and what gets written into the optimiser
+(init_from_pts3d :83-126) follow the reference.  It is a one-off O(E*P) host-orchestrated step, not the inner loop.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .commons import rotmat_to_unitquat, signed_log1p
+
+
+# ------------------------------------------------------------------------------------------------ small solvers
+def rigid_points_registration(x, y, w):
+    """Weighted Umeyama: (s, R, T) minimising sum w |s R x + T - y|^2 for x, y [P,3], w [P]."""
+    x, y, w = x.reshape(-1, 3).double(), y.reshape(-1, 3).double(), w.reshape(-1).double()
+    w = w / w.sum()
+    xm, ym = (w[:, None] * x).sum(0), (w[:, None] * y).sum(0)
+    xc, yc = x - xm, y - ym
+    var_x = (w * xc.square().sum(-1)).sum()
+    cov = (yc * w[:, None]).T @ xc                           # 3x3
+    U, S, Vt = torch.linalg.svd(cov.cpu())
+    d = torch.ones(3, dtype=torch.float64)
+    d[2] = torch.sign(torch.det(U @ Vt))
+    R = (U * d) @ Vt
+    s = float((S * d).sum() / var_x.cpu())
+    T = ym.cpu() - s * (R @ xm.cpu())
+    return s, R.float(), T.float()
+
+
+def sRT_to_4x4(scale, R, T, device):
+    trf = torch.eye(4, device=device)
+    trf[:3, :3] = torch.as_tensor(R, device=device) * scale
+    trf[:3, 3] = torch.as_tensor(T, device=device).ravel()
+    return trf
+
+
+def geotrf(trf, pts):
+    return pts @ trf[:3, :3].T + trf[:3, 3]
+
+
+def estimate_focal(pts3d_i):
+    """Weiszfeld focal of one pointmap [H,W,3] with the principal point at the centre (post_process.py:36-60)."""
+    H, W, _ = pts3d_i.shape
+    dev = pts3d_i.device
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
+    pixels = torch.stack((xs - W / 2, ys - H / 2), -1).reshape(-1, 2).float()
+    p = pts3d_i.reshape(-1, 3)
+    xy_over_z = (p[:, :2] / p[:, 2:3]).nan_to_num(posinf=0, neginf=0)
+    dot_xy_px = (xy_over_z * pixels).sum(-1)
+    dot_xy_xy = xy_over_z.square().sum(-1)
+    focal = dot_xy_px.mean() / dot_xy_xy.mean()
+    for _ in range(10):
+        dis = (pixels - focal * xy_over_z).norm(dim=-1)
+        wgt = dis.clip(min=1e-8).reciprocal()
+        focal = (wgt * dot_xy_px).mean() / (wgt * dot_xy_xy).mean()
+    return float(focal)
+
+
+def linear_pnp(pts3d, focal, msk, pp=None, irls_rounds=2):
+    """Camera-to-world pose of an image whose pixels see the world points pts3d [H,W,3] (stands in for fast_pnp :442-482).
+    Direct linear transform on the calibrated rays, Procrustes projection of the 3x3 block, IRLS on the ray residual."""
+    H, W, _ = pts3d.shape
+    if int(msk.sum()) < 6:
+        return None
+    dev = pts3d.device
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
+    pp = (W / 2, H / 2) if pp is None else pp
+    rays = torch.stack(((xs - pp[0]) / focal, (ys - pp[1]) / focal, torch.ones_like(xs, dtype=torch.float32)), -1)[msk].double()
+    X = pts3d[msk].double()
+    Xh = torch.cat((X, torch.ones_like(X[:, :1])), -1)                       # [n,4]
+    wgt = torch.ones(len(X), dtype=torch.float64, device=dev)
+    best = None
+    for _ in range(1 + irls_rounds):
+        # r x (P Xh) = 0  ->  two independent rows per point, unknown p = vec(P) (3x4, world -> camera)
+        rx, ry = rays[:, 0:1], rays[:, 1:2]
+        zero = torch.zeros_like(Xh)
+        A1 = torch.cat((Xh, zero, -rx * Xh), -1)
+        A2 = torch.cat((zero, Xh, -ry * Xh), -1)
+        A = torch.cat((A1 * wgt[:, None], A2 * wgt[:, None]), 0)
+        M = (A.T @ A).cpu()
+        evals, evecs = torch.linalg.eigh(M)
+        Pm = evecs[:, 0].reshape(3, 4)
+        U, S, Vt = torch.linalg.svd(Pm[:, :3])
+        sgn = torch.sign(torch.det(U @ Vt))
+        R = sgn * (U @ Vt)
+        scale = sgn * S.mean()
+        t = Pm[:, 3] / scale
+        Rd, td = R.to(dev), t.to(dev)
+        cam = X @ Rd.T + td
+        if float((cam[:, 2] > 0).double().mean()) < 0.5:                      # points must lie in front of the camera
+            R, t = -R, -t
+            R = R @ torch.diag(torch.tensor([1., 1., 1.], dtype=torch.float64))
+            Rd, td = R.to(dev), t.to(dev)
+            cam = X @ Rd.T + td
+        res = (cam[:, :2] / cam[:, 2:3].clamp(min=1e-9) - rays[:, :2]).norm(dim=-1) * focal      # reprojection error in pixels
+        best = (R, t)
+        wgt = 1.0 / res.clamp(min=1.0)                                        # Huber-like: down-weight > 1 px
+    R, t = best
+    if float(torch.det(R)) < 0:
+        return None
+    w2c = torch.eye(4, dtype=torch.float64)
+    w2c[:3, :3], w2c[:3, 3] = R, t
+    return focal, torch.linalg.inv(w2c).float().to(dev)
+
+
+# ------------------------------------------------------------------------------------------------ the tree
+def compute_edge_scores(edges, conf_i, conf_j):
+    """mean(conf_i) * mean(conf_j) per edge (commons.py:20-25); conf_* [E,P]."""
+    si, sj = conf_i.mean(-1), conf_j.mean(-1)
+    return {tuple(e): float(si[k] * sj[k]) for k, e in enumerate(edges)}
+
+
+def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_conf, min_conf_thr, device, init_priors=None,
+                          has_im_poses=True, verbose=True):
+    """pred_* [E,H,W,3], conf_* [E,H,W] device tensors.  Returns (pts3d list, msp_edges, im_focals list, im_poses [N,4,4])."""
+    n_imgs = len(imshapes)
+    E = len(edges)
+    eidx = {tuple(e): k for k, e in enumerate(edges)}
+    scores = compute_edge_scores(edges, conf_i.reshape(E, -1), conf_j.reshape(E, -1))
+    graph = sp.dok_array((n_imgs, n_imgs))
+    for (i, j), v in scores.items():
+        graph[i, j] = -v
+    msp = sp.csgraph.minimum_spanning_tree(graph).tocoo()
+    todo = sorted(zip(-msp.data, msp.row.tolist(), msp.col.tolist()))
+    pts3d = [None] * n_imgs
+    im_poses = [None] * n_imgs
+    im_focals = [None] * n_imgs
+    if init_priors is None:
+        score, i, j = todo.pop()
+    else:
+        while todo:
+            score, i, j = todo.pop()
+            if i == 0 or j == 0:
+                break
+            todo.insert(0, (score, i, j))
+    if verbose:
+        print(f' init edge ({i}*,{j}*) {score=}')
+    k = eidx[(i, j)]
+    pts3d[i], pts3d[j] = pred_i[k].clone(), pred_j[k].clone()
+    done = {i, j}
+    if has_im_poses:
+        if init_priors is None:
+            im_poses[i] = torch.eye(4, device=device)
+            im_focals[i] = estimate_focal(pred_i[k])
+        else:
+            keypose = torch.as_tensor(np.array(init_priors[0]).astype(np.float32), device=device)
+            keyfocal = float(init_priors[2][0])
+            if i == 0:
+                im_poses[i], im_focals[i] = keypose, keyfocal
+                pts3d[i], pts3d[j] = geotrf(keypose, pts3d[i]), geotrf(keypose, pts3d[j])
+            elif j == 0:
+                im_poses[j], im_focals[j] = keypose, keyfocal
+                kk = eidx[(j, i)]
+                pts3d[i], pts3d[j] = geotrf(keypose, pred_j[kk].clone()), geotrf(keypose, pred_i[kk].clone())
+    msp_edges = [(i, j)]
+    last_k = k
+    while todo:
+        score, i, j = todo.pop()
+        if im_focals[i] is None:
+            im_focals[i] = estimate_focal(pred_i[last_k])      # the reference uses the PREVIOUS edge's map here (:199)
+        if i in done:
+            assert j not in done
+            k = last_k = eidx[(i, j)]
+            s, R, T = rigid_points_registration(pred_i[k], pts3d[i], conf_i[k])
+            pts3d[j] = geotrf(sRT_to_4x4(s, R, T, device), pred_j[k])
+            done.add(j)
+            msp_edges.append((i, j))
+            if has_im_poses and im_poses[i] is None:
+                im_poses[i] = sRT_to_4x4(1, R, T, device)
+        elif j in done:
+            assert i not in done
+            k = last_k = eidx[(i, j)]
+            s, R, T = rigid_points_registration(pred_j[k], pts3d[j], conf_j[k])
+            pts3d[i] = geotrf(sRT_to_4x4(s, R, T, device), pred_i[k])
+            done.add(i)
+            msp_edges.append((i, j))
+            if has_im_poses and im_poses[i] is None:
+                im_poses[i] = sRT_to_4x4(1, R, T, device)
+        else:
+            todo.insert(0, (score, i, j))
+    if has_im_poses:
+        order = sorted(scores.items(), key=lambda kv: -kv[1])
+        for (i, j), _ in order:
+            if im_focals[i] is None:
+                im_focals[i] = estimate_focal(pred_i[eidx[(i, j)]])
+        for i in range(n_imgs):
+            if im_poses[i] is None:
+                msk = (im_conf[i] > min_conf_thr).to(device)
+                res = linear_pnp(pts3d[i], im_focals[i], msk)
+                if res:
+                    im_focals[i], im_poses[i] = res
+            if im_poses[i] is None:
+                im_poses[i] = torch.eye(4, device=device)
+        im_poses = torch.stack(im_poses)
+    else:
+        im_poses = im_focals = None
+    return pts3d, msp_edges, im_focals, im_poses
+
+
+def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
+    """init_minimum_spanning_tree + init_from_pts3d (:69-126) on a mirror PointCloudOptimizer that is already on a device."""
+    eng = scene._need_engine()
+    dev = eng.device
+    H, W = scene.imshape
+    E, N = len(scene.edges), scene.n_imgs
+    pred_i, pred_j = eng.pred_i.reshape(E, H, W, 3), eng.pred_j.reshape(E, H, W, 3)
+    conf_i, conf_j = scene._raw_conf_i.to(dev), scene._raw_conf_j.to(dev)
+    pts3d, _, im_focals, im_poses = minimum_spanning_tree(scene.imshapes, scene.edges, pred_i, pred_j, conf_i, conf_j, scene.im_conf,
+                                                          scene.min_conf_thr, dev, init_priors=init_priors, verbose=scene.verbose)
+    # ---- init_from_pts3d (:83-126); the known-poses branch (nkp > 1) re-aligns everything on the preset poses
+    if not eng.flags['train_poses']:
+        raise NotImplementedError("init='mst' with preset poses (align_multiple_poses, init_im_poses.py:88-99)")
+    pw = eng.params['pw_poses'].clone()
+    for e, (i, j) in enumerate(scene.edges):
+        s, R, T = rigid_points_registration(pred_i[e], pts3d[i], conf_i[e])
+        pw[e, 0:4] = rotmat_to_unitquat(R).to(dev)
+        pw[e, 4:7] = signed_log1p(T.to(dev) / s)
+        pw[e, 7] = float(np.log(s))
+    s_factor = float(torch.exp(np.log(scene.base_scale) - pw[:, 7].mean())) if scene.norm_pw_scale else 1.0
+    im_poses = im_poses.clone()
+    im_poses[:, :3, 3] *= s_factor
+    pts3d = [p * s_factor for p in pts3d]
+    poses = eng.params['im_poses'].clone()
+    depth = eng.params['depth'].clone()
+    focals = eng.params['im_focals'].clone()
+    for i in range(N):
+        c2w = im_poses[i]
+        if not scene.if_use_mono:
+            w2c = torch.linalg.inv(c2w)
+            d = geotrf(w2c, pts3d[i].reshape(-1, 3))[:, 2]
+            depth[i] = d.log().nan_to_num(neginf=0)
+        poses[i, 0:4] = rotmat_to_unitquat(c2w[:3, :3]).to(dev)
+        poses[i, 4:7] = signed_log1p(c2w[:3, 3])
+        if im_focals[i] is not None and eng.flags['train_focals'] and not getattr(eng, 'shared_focal', False):
+            focals[i] = scene.focal_break * float(np.log(im_focals[i]))
+    if getattr(eng, 'shared_focal', False) and eng.flags['train_focals'] and im_focals[0] is not None:
+        focals[0] = scene.focal_break * float(np.log(im_focals[0]))
+    eng.set_params(pw_poses=pw, depth=depth, im_poses=poses, im_focals=focals)
+    if scene.verbose:
+        print(' init loss =', float(scene()))

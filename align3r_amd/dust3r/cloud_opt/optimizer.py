@@ -5,8 +5,8 @@ constructor keywords, parameter names / parameterisation (pw_poses [E,8], im_dep
 im_poses [N,7], im_focals = focal_break*log f, im_pp), same random initial state for the same torch seed
 (parameters are drawn in the reference's order), same getters and the same optimisation loop
 (Adam betas (0.9, 0.9), cosine/linear schedule).  Gradients are analytic (the reference uses autograd).
-Not available here (raise NotImplementedError): init='mst'/'known_poses' (MST + PnP initialisation, SURVEY
-row N1), allow_pw_adaptors=True, mixed image shapes with different aspect (padding is supported by the
+init='mst' is available but PARITY UNPINNED (init_im_poses.py of this package: roma / cv2 are absent).
+Not available here (raise NotImplementedError): init='known_poses', allow_pw_adaptors=True, mixed image shapes with different aspect (padding is supported by the
 kernels, see a3r.h, but not wired through this class yet).
 """
 from __future__ import annotations
@@ -43,6 +43,7 @@ class PointCloudOptimizer:
         self.imshapes = get_imshapes(self.edges, self._pred_i, self._pred_j)
         self._conf_i = torch.as_tensor(pred1['conf']).float()
         self._conf_j = torch.as_tensor(pred2['conf']).float()
+        self._raw_conf_i, self._raw_conf_j = self._conf_i.cpu(), self._conf_j.cpu()     # kept for the MST initialisation
         self.min_conf_thr = min_conf_thr
         self.conf_trf = get_conf_trf(conf)
         # per-image confidence = max over the edges it appears in (base_opt.py:169-175)
@@ -287,12 +288,16 @@ class PointCloudOptimizer:
 
     def compute_global_alignment(self, init=None, init_priors=None, niter_PnP=10, lr=0.01, niter=300, schedule='cosine',
                                  lr_min=1e-6):
-        if init is not None:
-            if init in ('msp', 'mst', 'known_poses'):
-                raise NotImplementedError(f"init={init!r}: the MST / PnP initialisation (init_im_poses.py) is SURVEY row N1 "
-                                          "('next'); start from init=None or set the state with set_params()")
-            raise ValueError(f'bad value for {init=}')
         e = self._need_engine()
+        if init is None:
+            pass
+        elif init in ('msp', 'mst'):
+            from .init_im_poses import init_minimum_spanning_tree       # parity unpinned (see that module)
+            init_minimum_spanning_tree(self, init_priors=init_priors, niter_PnP=niter_PnP)
+        elif init == 'known_poses':
+            raise NotImplementedError("init='known_poses' (init_from_known_poses, init_im_poses.py:27-66) is not built")
+        else:
+            raise ValueError(f'bad value for {init=}')
         if schedule not in ('cosine', 'linear'):
             raise ValueError(f'bad lr {schedule=}')
         if niter <= 0:

@@ -114,11 +114,16 @@ class PointCloudOptimizer(_Base):
 
     def compute_global_alignment(self, init=None, init_priors=None, niter_PnP=10, lr=0.01, niter=300, schedule='cosine',
                                  lr_min=1e-3, **kw):
-        if init is not None:
-            if init in ('msp', 'mst', 'known_poses'):
-                raise NotImplementedError(f"init={init!r}: the MST / PnP initialisation is SURVEY row N1 ('next')")
-            raise ValueError(f'bad value for {init=}')
         e = self._need_engine()
+        if init is None:
+            pass
+        elif init in ('msp', 'mst'):
+            from ..cloud_opt.init_im_poses import init_minimum_spanning_tree       # parity unpinned (see that module)
+            init_minimum_spanning_tree(self, init_priors=init_priors, niter_PnP=niter_PnP)
+        elif init == 'known_poses':
+            raise NotImplementedError("init='known_poses' is not built")
+        else:
+            raise ValueError(f'bad value for {init=}')
         if niter <= 0:
             return float('inf')
         e.set_params(reset_optimizer=True)
