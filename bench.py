@@ -33,6 +33,21 @@ PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/
 FLOP_PER_PAIR = {(384, 512): 1969.1e9, (288, 512): 1436.1e9, (224, 224): 461.2e9}
 
 
+def pmc_traffic(kernel):
+    """HBM/fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, gfx950 correction applied).  PMC counters cannot be read from inside this
+    process, so this is the number of the profiled run of the same command, or None when no such file is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +157,9 @@ def main():
         "model_tflops_as_reference": round(pairs_per_s * flop_pair / 1e12 / world, 2) if flop_pair else None,
         "roofline": {"bound": "mfma", "kernel": "gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)", "achieved": round(achieved, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": None, "launches": lin["launches"], "avg_launch_us": round(1e3 * lin["ms"] / max(lin["launches"], 1), 2)},
+                     "traffic": pmc_traffic("gemm_kernel<0>") if (B, H, W) == (12, 384, 512) else None,
+                     "algorithmic_flop_per_launch": round(lin["work"] / max(lin["launches"], 1)),
+                     "launches": lin["launches"], "avg_launch_us": round(1e3 * lin["ms"] / max(lin["launches"], 1), 2)},
         "kernels": kernels,
     }
 
@@ -173,7 +190,8 @@ def main():
         res["align_iters_per_s"] = round(a.align_iters / dta, 2)
         res["align_config"] = {"N": N, "E": E, "P": P, "use_mono": False, "iters": a.align_iters}
         res["roofline_align"] = {"bound": "hbm", "kernel": "align_main_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                 "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                 "traffic": pmc_traffic("align_main_kernel") if (a.frames, E, P) == (16, 84, 196608) else None,
                                  "bytes_per_iter": pa["work"] / max(pa["launches"], 1), "avg_launch_us": round(1e3 * pa["ms"] / max(pa["launches"], 1), 2)}
         del al
 
