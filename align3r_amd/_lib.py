@@ -83,6 +83,9 @@ SIGNATURES = {
     "a3r_model_finalize": (C.c_int, [c_void, c_void, C.c_size_t, c_void]),
     "a3r_model_workspace_bytes": (C.c_size_t, [c_void, C.c_int, C.c_int, C.c_int]),
     "a3r_model_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
+    "a3r_model_encode_workspace_bytes": (C.c_size_t, [c_void, C.c_int, C.c_int, C.c_int]),
+    "a3r_model_encode": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, c_void]),
+    "a3r_model_decode": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
     "a3r_model_tap": (C.c_int, [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_size_t)]),
     "a3r_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "a3r_align_create": (C.c_int, [C.POINTER(AlignDesc), C.POINTER(c_void), c_void]),

@@ -33,8 +33,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a) {
     float* Vs = Ks + 2 * AK * ALD;                // [2][AK][ALD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = lane & 31, half = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q_row = blockIdx.x * AQ + wave * 32 + qi;
+    // XCD-aware mapping: the query blocks of one (batch, head) re-read the same K/V; workgroup ids are dealt
+    // round-robin over the 8 XCDs (private L2s), so give all query blocks of a head to ONE XCD.
+    const int nqb = (a.Nq + AQ - 1) / AQ;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int group = (seq / nqb) * 8 + xcd, qb = seq - (seq / nqb) * nqb;
+    if (group >= a.B * a.H) return;                 // uniform per workgroup
+    const int h = group % a.H, b = group / a.H;
+    const int q_row = qb * AQ + wave * 32 + qi;
     const int q_ld = q_row < a.Nq ? q_row : a.Nq - 1;
 
     // Q fragment (B operand of S^T = K Q^T): lane holds Q[q][8*kb + 4*half + t], pre-scaled by hd^-0.5
@@ -185,7 +191,8 @@ extern "C" int a3r_attention(const float* q, int ldq, const float* k, int ldk, c
         attr_done = true;
     }
     AttnArgs a = {q, k, v, o, ldq, ldk, ldv, ldo, B, H, Nq, Nk};
-    dim3 grid((Nq + AQ - 1) / AQ, H, B);
+    const int nqb = (Nq + AQ - 1) / AQ, groups = B * H;
+    dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), ATTN_LDS_BYTES, as_stream(stream), a);
     A3R_LAUNCH_CHECK();

@@ -418,9 +418,12 @@ float* fusion(Plan& P, const FusionW& w, const float* x0, const float* x1, bool 
     return r;
 }
 
+// phase: 0 = whole forward from images; 1 = encoder only (img1 [B,...] -> feat_out [B,N,E]);
+//        2 = decoder + heads from cached encoder features (feat1_in / feat2_in [B,N,E]).
 int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, const float* pd1, const float* pd2, int B,
              int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, void* ws, size_t ws_bytes, void* stream,
-             size_t* peak) {
+             size_t* peak, int phase = 0, const float* feat1_in = nullptr, const float* feat2_in = nullptr,
+             float* feat_out = nullptr) {
     const a3r_model_config& c = m->cfg;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, F = c.feature_dim, L = c.last_dim;
     const int nh = H / 16, nw = W / 16, N = nh * nw, BN = B * N, M2 = 2 * BN;
@@ -428,6 +431,28 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     P.m = m; P.stream = stream;
     P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};
     Arena& ar = P.ar;
+    if (phase == 1) {
+        // ---------------- encoder only, B images (_encode_image model.py:151-163): per-frame features for caching.
+        // The reference re-encodes a frame for every pair it appears in; the result does not depend on the pair.
+        float* cols = ar.alloc((size_t)BN * 768);
+        float* x = ar.alloc((size_t)BN * E);
+        float* xn = ar.alloc((size_t)BN * E);
+        float* qkv = ar.alloc((size_t)BN * 3 * E);
+        float* att = ar.alloc((size_t)BN * E);
+        float* hid = ar.alloc((size_t)BN * E * c.mlp_ratio);
+        if (!dry) {
+            const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
+            if ((P.rc = a3r_patchify(img1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+        }
+        P.linear(cols, 768, m->pe_w, x, E, BN, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
+        for (int i = 0; i < c.enc_depth; i++) {
+            P.self_block(m->enc[i], x, x, BN, E, c.enc_num_heads, N, nw, E * c.mlp_ratio, xn, qkv, att, hid);
+            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, BN, E, E * c.mlp_ratio, xn, hid);
+        }
+        P.ln(x, m->encn_w, m->encn_b, dry ? nullptr : feat_out, BN, E);
+        if (peak) *peak = ar.peak;
+        return P.rc;
+    }
     // ---------------- persistent buffers
     float* feat = ar.alloc((size_t)M2 * E);       // enc_norm output = level 0
     float* pc = ar.alloc((size_t)M2 * D);
@@ -436,7 +461,20 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     float* dec_last = ar.alloc((size_t)M2 * D);
     const size_t mark = ar.off;
     // ---------------- encoder (model.py:151-163)
-    {
+    if (phase == 2) {
+        // cached per-frame features: gather the two views' rows into the [2*B*N, E] layout the decoder expects
+        float* cols = ar.alloc((size_t)M2 * 768);
+        if (!dry) {
+            const size_t bytes = (size_t)BN * E * sizeof(float);
+            hipError_t e1 = hipMemcpyAsync(feat, feat1_in, bytes, hipMemcpyDeviceToDevice, as_stream(stream));
+            hipError_t e2 = hipMemcpyAsync(feat + (size_t)BN * E, feat2_in, bytes, hipMemcpyDeviceToDevice, as_stream(stream));
+            if (e1 != hipSuccess || e2 != hipSuccess) { set_error("a3r_model_decode: feature copy failed"); return A3R_EHIP; }
+            const long sb = 3L * H * W, sc = 1, sy = 3L * W, sx = 3;
+            if ((P.rc = a3r_patchify(pd1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+            if ((P.rc = a3r_patchify(pd2, cols + (size_t)BN * 768, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
+        }
+        P.linear(cols, 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
+    } else {
         float* cols = ar.alloc((size_t)M2 * 768);
         float* x = ar.alloc((size_t)M2 * E);
         float* xn = ar.alloc((size_t)M2 * E);
@@ -628,6 +666,49 @@ extern "C" int a3r_model_forward(a3r_model_t m, const float* img1, const float* 
     const size_t need_bytes = a3r_model_workspace_bytes(m, B, H, W);
     A3R_CHECK_ARG(workspace_bytes >= need_bytes, "a3r_model_forward: workspace too small (%zu < %zu)", workspace_bytes, need_bytes);
     return run_plan(m, false, img1, img2, pd1, pd2, B, H, W, pts1, conf1, pts2, conf2, workspace, workspace_bytes, stream, nullptr);
+}
+
+static int check_forward_args(a3r_model_t m, int B, int H, int W, const void* workspace, const char* who) {
+    A3R_CHECK_ARG(m, "%s: null handle", who);
+    if (!m->finalized) {
+        set_error("%s: a3r_model_finalize has not been called", who);
+        return A3R_ESTATE;
+    }
+    A3R_CHECK_ARG(workspace, "%s: null workspace", who);
+    A3R_CHECK_ARG(B > 0, "%s: batch must be positive", who);
+    A3R_CHECK_ARG(H > 0 && H % 16 == 0, "Input image height (%d) is not a multiple of patch size (16).", H);
+    A3R_CHECK_ARG(W > 0 && W % 16 == 0, "Input image width (%d) is not a multiple of patch size (16).", W);
+    A3R_CHECK_ARG(H / 16 < a3r_model_s::MAX_POS && W / 16 < a3r_model_s::MAX_POS, "%s: image too large for the RoPE table", who);
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "%s: workspace must be 256-byte aligned", who);
+    return A3R_OK;
+}
+
+extern "C" size_t a3r_model_encode_workspace_bytes(a3r_model_t m, int B, int H, int W) {
+    if (!m || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return 0;
+    size_t peak = 0;
+    run_plan(m, true, nullptr, nullptr, nullptr, nullptr, B, H, W, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &peak, 1);
+    return peak;
+}
+
+extern "C" int a3r_model_encode(a3r_model_t m, const float* img, int B, int H, int W, float* feat_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (int rc = check_forward_args(m, B, H, W, workspace, "a3r_model_encode")) return rc;
+    A3R_CHECK_ARG(img && feat_out, "a3r_model_encode: null pointer");
+    const size_t need_bytes = a3r_model_encode_workspace_bytes(m, B, H, W);
+    A3R_CHECK_ARG(workspace_bytes >= need_bytes, "a3r_model_encode: workspace too small (%zu < %zu)", workspace_bytes, need_bytes);
+    return run_plan(m, false, img, nullptr, nullptr, nullptr, B, H, W, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                    stream, nullptr, 1, nullptr, nullptr, feat_out);
+}
+
+extern "C" int a3r_model_decode(a3r_model_t m, const float* feat1, const float* feat2, const float* pd1, const float* pd2, int B,
+                                int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (int rc = check_forward_args(m, B, H, W, workspace, "a3r_model_decode")) return rc;
+    A3R_CHECK_ARG(feat1 && feat2 && pd1 && pd2 && pts1 && conf1 && pts2 && conf2, "a3r_model_decode: null pointer");
+    const size_t need_bytes = a3r_model_workspace_bytes(m, B, H, W);      // the whole-forward plan bounds the decode plan
+    A3R_CHECK_ARG(workspace_bytes >= need_bytes, "a3r_model_decode: workspace too small (%zu < %zu)", workspace_bytes, need_bytes);
+    return run_plan(m, false, nullptr, nullptr, pd1, pd2, B, H, W, pts1, conf1, pts2, conf2, workspace, workspace_bytes, stream,
+                    nullptr, 2, feat1, feat2, nullptr);
 }
 
 extern "C" int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count) {

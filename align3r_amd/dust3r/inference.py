@@ -37,14 +37,46 @@ def check_if_same_size(pairs):
     return all(shapes1[0] == s for s in shapes1) and all(shapes2[0] == s for s in shapes2)
 
 
+def _inference_cached(pairs, model, device, batch_size, keep_on_device):
+    """Encode every distinct frame once (keyed by view['idx']), then run decoders + heads per batch of pairs."""
+    frames = {}
+    for v1, v2 in pairs:
+        frames.setdefault(v1['idx'], v1)
+        frames.setdefault(v2['idx'], v2)
+    keys = list(frames)
+    feats = {}
+    for i in range(0, len(keys), batch_size):
+        chunk = keys[i:i + batch_size]
+        f = model.encode_frames(torch.cat([frames[k]['img'] for k in chunk]))
+        for k, fk in zip(chunk, f):
+            feats[k] = fk
+    result = []
+    for i in range(0, len(pairs), batch_size):
+        view1, view2 = collate_with_cat(pairs[i:i + batch_size])
+        for view in (view1, view2):
+            for name in view.keys():
+                if name not in _IGNORE_KEYS:
+                    view[name] = view[name].to(device, non_blocking=True)
+        f1 = torch.stack([feats[v1['idx']] for v1, _ in pairs[i:i + batch_size]])
+        f2 = torch.stack([feats[v2['idx']] for _, v2 in pairs[i:i + batch_size]])
+        pred1, pred2 = model.forward_cached(view1, view2, f1, f2)
+        res = dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
+        result.append(res if keep_on_device else to_cpu(res))
+    return collate_with_cat(result)
+
+
 @torch.no_grad()
-def inference(pairs, model, device, batch_size=8, verbose=True, keep_on_device=False):
+def inference(pairs, model, device, batch_size=8, verbose=True, keep_on_device=False, cache_encoder=False):
+    """cache_encoder=True (extension): encode each frame once instead of once per pair -- identical outputs,
+    about half the arithmetic on a window graph.  Frames are identified by view['idx']."""
     if verbose:
         print(f'>> Inference with model on {len(pairs)} image pairs')
     result = []
     multiple_shapes = not check_if_same_size(pairs)
     if multiple_shapes:
         batch_size = 1
+    if cache_encoder and not multiple_shapes and hasattr(model, 'encode_frames'):
+        return _inference_cached(pairs, model, device, batch_size, keep_on_device)
     rng = range(0, len(pairs), batch_size)
     if verbose:
         try:

@@ -209,6 +209,25 @@ class AsymmetricCroCo3DStereo:
         return res1, res2
 
 
+    # ------------------------------------------------------------------ encoder feature caching (extension)
+    def encode_frames(self, imgs):
+        """_encode_image (model.py:151-163) for a batch of frames [B,3,H,W]: enc_norm'd tokens [B,N,enc_embed_dim].
+        The encoder output depends on the frame only, so a clip needs it once per frame, not once per pair."""
+        if self._engine is None:
+            raise RuntimeError('the model is not on a HIP device -- call .to("cuda")')
+        return self._engine.encode(imgs.to(self.device, torch.float32).contiguous())
+
+    def forward_cached(self, view1, view2, feat1, feat2):
+        """forward() with the two views' encoder features given (same outputs, bit-identical)."""
+        if self._engine is None:
+            raise RuntimeError('the model is not on a HIP device -- call .to("cuda")')
+        H, W = view1['img'].shape[-2:]
+        f = lambda t: t.to(self.device, torch.float32).contiguous()
+        out = self._engine.decode(feat1, feat2, f(view1['pred_depth']), f(view2['pred_depth']), H, W)
+        return (dict(pts3d=out['pts3d_1'], conf=out['conf_1'], pred_mask=0),
+                dict(pts3d_in_other_view=out['pts3d_2'], conf=out['conf_2'], pred_mask=0))
+
+
 def save_checkpoint(path, model: AsymmetricCroCo3DStereo, img_size=(512, 512), epoch=0):
     """Write a reference-format checkpoint (croco/utils/misc.py:292-305) for `model`."""
     from ..weights import model_string

@@ -81,6 +81,38 @@ class PairEngine:
                                              ptr(self.workspace), self.workspace.numel(), stream_ptr()), "a3r_model_forward")
         return out
 
+    def _workspace(self, need):
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.workspace
+
+    def encode(self, img):
+        """Encoder features of B frames [B,3,H,W] -> [B, N, enc_embed_dim] (for per-frame caching)."""
+        B, _, H, W = img.shape
+        with torch.cuda.device(self.device):
+            need = int(self.lib.a3r_model_encode_workspace_bytes(self.handle, B, H, W))
+            if need == 0:
+                raise RuntimeError(f"Input image size ({H}x{W}) is not a multiple of patch size (16).")
+            ws = self._workspace(need)
+            feat = torch.empty((B, (H // 16) * (W // 16), self.cfg.enc_embed_dim), device=self.device)
+            check(self.lib.a3r_model_encode(self.handle, ptr(img.contiguous()), B, H, W, ptr(feat), ptr(ws), ws.numel(), stream_ptr()),
+                  "a3r_model_encode")
+        return feat
+
+    def decode(self, feat1, feat2, pd1, pd2, H, W, out=None):
+        """Decoders + heads for B pairs from cached encoder features (same outputs as forward)."""
+        B = feat1.shape[0]
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.workspace_bytes(B, H, W))
+            if out is None:
+                out = dict(pts3d_1=torch.empty((B, H, W, 3), device=self.device), conf_1=torch.empty((B, H, W), device=self.device),
+                           pts3d_2=torch.empty((B, H, W, 3), device=self.device), conf_2=torch.empty((B, H, W), device=self.device))
+            check(self.lib.a3r_model_decode(self.handle, ptr(feat1.contiguous()), ptr(feat2.contiguous()), ptr(pd1.contiguous()),
+                                            ptr(pd2.contiguous()), B, H, W, ptr(out["pts3d_1"]), ptr(out["conf_1"]), ptr(out["pts3d_2"]),
+                                            ptr(out["conf_2"]), ptr(ws), ws.numel(), stream_ptr()), "a3r_model_decode")
+        return out
+
     def tap(self, name, cols):
         """Intermediate tensor of the last forward as a [rows, cols] view of the workspace (parity tests)."""
         p = C.c_void_p()

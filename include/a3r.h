@@ -175,6 +175,17 @@ size_t a3r_model_workspace_bytes(a3r_model_t m, int B, int H, int W);
 int a3r_model_forward(a3r_model_t m, const float* img1, const float* img2, const float* pd1, const float* pd2,
                       int B, int H, int W, float* pts1, float* conf1, float* pts2, float* conf2,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* Encoder feature caching (an algorithmic saving the reference does not have: it re-encodes each frame once per
+ * pair, dust3r/inference.py:66 + model.py:165-174, although the encoder output depends on the frame only).
+ * a3r_model_encode: B frames img [B,3,H,W] -> enc_norm'd tokens feat_out [B, (H/16)*(W/16), enc_embed_dim].
+ * a3r_model_decode: the rest of forward() for B pairs from cached features feat1/feat2 [B, N, enc_embed_dim]
+ * (workspace >= a3r_model_workspace_bytes).  encode + decode is bit-identical to a3r_model_forward. */
+size_t a3r_model_encode_workspace_bytes(a3r_model_t m, int B, int H, int W);
+int a3r_model_encode(a3r_model_t m, const float* img, int B, int H, int W, float* feat_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int a3r_model_decode(a3r_model_t m, const float* feat1, const float* feat2, const float* pd1, const float* pd2, int B,
+                     int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* Debug taps for the parity tests: copies of intermediate tensors inside the workspace after a forward.
  * name in {"enc1","dec1_6","dec1_last","dec2_last","pc_tokens","raw1"}; returns device pointer + element count. */
 int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count);

@@ -197,3 +197,16 @@ def test_mst_initialisation_recovers_geometry(model):
         assert np.abs(rel[n][:3, 3] / scale - gt[n][:3, 3]).max() < 0.05 * np.linalg.norm(gt[N - 1][:3, 3]), n
     final = scene.compute_global_alignment(init=None, niter=50, schedule="cosine", lr=0.01)
     assert final <= loss_init * 1.05
+
+
+def test_encoder_cache_is_bit_identical(model):
+    """inference(cache_encoder=True) encodes each frame once; outputs must equal the per-pair path bit for bit."""
+    from dust3r.image_pairs import make_pairs
+    from dust3r.inference import inference
+    views = _views(5, 48, 64, seed=7)
+    pairs = make_pairs(views, scene_graph="swin-2-noncyclic", symmetrize=True)
+    a = inference(pairs, model, "cuda", batch_size=4, verbose=False)
+    b = inference(pairs, model, "cuda", batch_size=4, verbose=False, cache_encoder=True)
+    for side, key in (("pred1", "pts3d"), ("pred1", "conf"), ("pred2", "pts3d_in_other_view"), ("pred2", "conf")):
+        assert torch.equal(a[side][key], b[side][key]), (side, key)
+    assert a["view1"]["idx"] == b["view1"]["idx"]
