@@ -161,6 +161,8 @@ class AlignEngine:
                          pw_adaptors=pw_adaptors).items():
             if v is not None:
                 t = torch.as_tensor(v, dtype=torch.float32).to(self.device)
+                if k == "im_focals" and self.shared_focal:
+                    t = t.reshape(-1)[:1]          # one focal shared by all images (optimizer.py:56-58)
                 self.params[k].copy_(t.reshape(self.params[k].shape))
         if reset_optimizer:
             for t in self.adam.values():

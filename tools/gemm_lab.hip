@@ -64,8 +64,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_lab(const float* __restrict
     const int nk = K / BK;
     load_tile(0);
     store_tile(0);
+    if (VAR & 16) { if (nk > 1) load_tile(BK); }
     __syncthreads();
     const int frow = lane & 31, fk = (lane >> 5) * 4;
+    if (VAR & 16) {
+        // software pipeline: at the top of iteration kt the registers hold slab kt+1 (loaded during kt-1); write it to
+        // the other LDS buffer right away (that buffer was last read in kt-1, all waves passed the barrier since),
+        // then reuse the registers for slab kt+2.  The end of the iteration is a bare barrier.
+        for (int kt = 0; kt < nk; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            if (kt + 2 < nk) load_tile((kt + 2) * BK);
+            const float* Ab = As + (buf * BM + wm * (BM / WM) + frow) * LDP + fk;
+            const float* Bb = Bs + (buf * BN + wn * (BN / WN) + frow) * LDP + fk;
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDP + kb * 8);
+#pragma unroll
+                for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDP + kb * 8);
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    } else
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
@@ -149,8 +178,8 @@ double run(const char* name, const float* A, const float* W, float* C, int M, in
 }
 
 int main() {
-    const int shapes[][3] = {{4096, 4096, 4096}, {6144, 4096, 1024}, {6144, 3072, 1024}, {6144, 1024, 1024}, {6144, 1024, 4096},
-                             {3072, 768, 768}, {3072, 2304, 768}, {3072, 768, 3072}, {6144, 768, 768}};
+    const int shapes[][3] = {{4096, 4096, 4096}, {18432, 4096, 1024}, {18432, 3072, 1024}, {18432, 1024, 1024}, {18432, 1024, 4096},
+                             {18432, 768, 768}, {18432, 768, 3072}};
     size_t maxA = 0, maxW = 0, maxC = 0;
     for (auto& s : shapes) {
         maxA = std::max(maxA, (size_t)s[0] * s[2]); maxW = std::max(maxW, (size_t)s[1] * s[2]); maxC = std::max(maxC, (size_t)s[0] * s[1]);
@@ -168,13 +197,13 @@ int main() {
         run<128, 128, 2, 2, 0>("128x128 4w base", A, W, Cref, M, N, K, it);
         run<128, 128, 2, 2, 1>("128x128 4w prio", A, W, C, M, N, K, it);
         run<128, 128, 2, 2, 2>("128x128 4w nopred", A, W, C, M, N, K, it);
-        run<128, 128, 2, 2, 6>("128x128 4w nopred+preload", A, W, C, M, N, K, it);
-        run<128, 128, 2, 2, 7>("128x128 4w nopred+preload+prio", A, W, C, M, N, K, it);
-        run<256, 128, 4, 2, 2>("256x128 8w nopred", A, W, C, M, N, K, it);
-        run<256, 128, 4, 2, 6>("256x128 8w nopred+preload", A, W, C, M, N, K, it);
+        run<128, 128, 2, 2, 18>("128x128 4w nopred early-write pipe", A, W, C, M, N, K, it);
+        run<128, 128, 2, 2, 19>("128x128 4w nopred pipe+prio", A, W, C, M, N, K, it);
+        run<256, 128, 4, 2, 18>("256x128 8w nopred pipe", A, W, C, M, N, K, it);
         run<128, 64, 2, 2, 2>("128x64 4w nopred", A, W, C, M, N, K, it);
+        run<128, 64, 2, 2, 18>("128x64 4w nopred pipe", A, W, C, M, N, K, it);
         run<64, 64, 2, 2, 2>("64x64 4w nopred", A, W, C, M, N, K, it);
-        run<64, 128, 2, 2, 2>("64x128 4w nopred", A, W, C, M, N, K, it);
+        run<64, 64, 2, 2, 18>("64x64 4w nopred pipe", A, W, C, M, N, K, it);
         // correctness of the last variant vs base on a few entries
         std::vector<float> c0(64), c1(64);
         CK(hipMemcpy(c0.data(), Cref + (size_t)(M - 1) * N + N - 64, 256, hipMemcpyDeviceToHost));
