@@ -2,13 +2,15 @@
 // final 1x1 conv + postprocess, weight repacking.  All fp32, 16-byte vector accesses where the
 // layout allows, one wave per row for the row reductions (64-wide DPP/shuffle sums).
 #include "common.h"
+#include "bf3.h"
 #include <cmath>
 
 namespace a3r {
 
 // ------------------------------------------------------------------------------------------- LayerNorm
 // nn.LayerNorm(D, eps) (croco.py:34; blocks.py:118-123,180-185): one wave per row, row kept in registers.
-template <int VPL>   // float4 per lane: D = 256 * VPL
+// BF3: write the normalised row in bf3 form (bf3.h) instead of fp32 -- the input format of gemm_bf3.hip.
+template <int VPL, bool BF3>   // float4 per lane: D = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ y, int M,
                                                          int D, float eps) {
@@ -33,11 +35,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
     const f32x4* wr = reinterpret_cast<const f32x4*>(w);
     const f32x4* br = reinterpret_cast<const f32x4*>(b);
+    char* y3 = reinterpret_cast<char*>(y) + (size_t)row * D * 6;
 #pragma unroll
-    for (int i = 0; i < VPL; i++) yr[lane + 64 * i] = v[i] * rstd * wr[lane + 64 * i] + br[lane + 64 * i];
+    for (int i = 0; i < VPL; i++) {
+        const f32x4 o = v[i] * rstd * wr[lane + 64 * i] + br[lane + 64 * i];
+        if (BF3) bf3_store4(y3, (lane + 64 * i) * 4, o);
+        else yr[lane + 64 * i] = o;
+    }
 }
 
-// generic fallback (any D % 4 == 0): one wave per row, three passes over an L1/L2-resident row
+// generic fallback (any D % 4 == 0; D % 8 == 0 for BF3): one wave per row, three passes over an L1/L2-resident row
+template <bool BF3>
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ y, int M,
                                                                  int D, float eps) {
@@ -50,8 +58,18 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
     float ss = 0.f;
     for (int i = lane; i < D; i += 64) { const float c = xr[i] - mean; ss += c * c; }
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
-    float* yr = y + (size_t)row * D;
-    for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * w[i] + b[i];
+    if (BF3) {
+        char* y3 = reinterpret_cast<char*>(y) + (size_t)row * D * 6;
+        for (int i = lane * 4; i < D; i += 256) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (xr[i + j] - mean) * rstd * w[i + j] + b[i + j];
+            bf3_store4(y3, i, o);
+        }
+    } else {
+        float* yr = y + (size_t)row * D;
+        for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * w[i] + b[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------- RoPE-2D (standalone)
@@ -189,19 +207,32 @@ static inline int grid_for(long total, int block = 256) {
 }  // namespace a3r
 using namespace a3r;
 
+template <bool BF3>
+static int launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps, void* stream) {
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PK_LAYERNORM, (BF3 ? 10.0 : 8.0) * M * D, st);
+    dim3 grid((M + 3) / 4), block(256);
+    if (D == 1024) hipLaunchKernelGGL((layernorm_kernel<4, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (D == 768) hipLaunchKernelGGL((layernorm_kernel<3, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (D == 256) hipLaunchKernelGGL((layernorm_kernel<1, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_generic_kernel<BF3>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
 extern "C" int a3r_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps,
                              void* stream) {
     A3R_CHECK_ARG(x && w && b && y, "a3r_layernorm: null pointer");
     A3R_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0, "a3r_layernorm: bad shape M=%d D=%d", M, D);
-    hipStream_t st = as_stream(stream);
-    ProfScope prof(PK_LAYERNORM, 8.0 * M * D, st);
-    dim3 grid((M + 3) / 4), block(256);
-    if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (D == 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (D == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps);
-    A3R_LAUNCH_CHECK();
-    return A3R_OK;
+    return launch_layernorm<false>(x, w, b, y, M, D, eps, stream);
+}
+
+extern "C" int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps,
+                                 void* stream) {
+    A3R_CHECK_ARG(x && w && b && y3, "a3r_layernorm_bf3: null pointer");
+    A3R_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "a3r_layernorm_bf3: bad shape M=%d D=%d (D must be a multiple of 8)", M, D);
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(y3) & 15) == 0, "a3r_layernorm_bf3: y3 must be 16-byte aligned");
+    return launch_layernorm<true>(x, w, b, static_cast<float*>(y3), M, D, eps, stream);
 }
 
 extern "C" int a3r_rope2d(float* tokens, const int64_t* positions, int B, int N, int H, int D, float base, float fwd,

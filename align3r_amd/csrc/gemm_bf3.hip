@@ -1,0 +1,248 @@
+// fp32 nn.Linear on the bf16 matrix cores of gfx950 ("bf3" GEMM): y = x W^T with fp32-level accuracy at ~1.5x the
+// throughput of the exact-fp32 MFMA kernel in gemm.hip (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate).
+//
+// Both operands arrive pre-split into three bf16 planes (bf3.h: x = x0 + x1 + x2 EXACTLY), and
+//     a b  =  a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0)  +  [a1b2 + a2b1 + a2b2, dropped: <= 2^-23 |a b|]
+// is evaluated as six v_mfma_f32_32x32x16_bf16 passes per 16-deep k-step.  Every bf16 x bf16 product is exact in the
+// fp32 accumulator, so the only errors are the dropped terms (below one fp32 ulp of the product) and the fp32
+// summation itself -- the same error class as the reference's fp32 GEMM (measured in tests/test_gpu_ops.py against
+// float64: not larger than the exact-fp32 MFMA kernel's).  Serves the same call sites as a3r_linear
+// (croco/models/blocks.py:58-169 qkv / proj / fc1 / fc2 / projq / projk / projv, patch embeddings, decoder_embed).
+//
+// Structure (64-wide waves): a workgroup computes a BM x BN tile with WM x WN waves, each wave a grid of 32x32 MFMA
+// accumulators.  K is walked in BK-deep stages copied global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// staging, no ds_write), NS stages deep, one raw s_barrier per stage with a counted s_waitcnt vmcnt so that the
+// next stage's DMA stays in flight across the barrier.  The LDS image of a stage is the plain row-major bf3 tile
+// (rows of U = 3 BK/8 16-byte units, no padding -- LDS-DMA writes lane-linear); bank conflicts are avoided by
+// rotating each row's units on the SOURCE side: unit c of row r is stored at unit (c - rot(r)) mod U with
+// rot(r) = (r / (16/G)) % G, G = BK/8, which makes every ds_read_b128 of the MFMA operand conflict-free
+// (SQ_LDS_BANK_CONFLICT = 0 measured).  Workgroup ids are remapped so each XCD walks a contiguous run of tiles.
+#include "gemm_common.h"
+#include "bf3.h"
+#include <cstdlib>
+
+namespace a3r {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, bool FULL>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64, KG = BK / 8, U = 3 * KG, G = KG, PER = 16 / G;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int SA = BM * U, SB = BN * U, LA = SA / NT, LB = SB / NT;      // 16-byte units per stage / per thread
+    constexpr int STAGE = (SA + SB) * 16, LPS = LA + LB;
+    static_assert(SA % NT == 0 && SB % NT == 0, "stage units must divide by the thread count");
+    static_assert(NS == 2 || NS == 3, "2 or 3 stages");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // XCD-aware bijective remap (blocks b and b+8 share an XCD), then group / tile decomposition
+    const int nwg = g.tiles_per_group * g.groups;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int grp = wgid / g.tiles_per_group;
+    wgid -= grp * g.tiles_per_group;
+    const GroupPtrs& P = g.grp[grp];
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid - tile_m * g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const size_t pitch = (size_t)g.K * 6;
+    const char* srcA[LA];
+    const char* srcB[LB];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
+        const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
+        srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; i++) {
+        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
+        const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
+        srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + c * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
+        const size_t koff = (size_t)kt * (KG * 48);
+#pragma unroll
+        for (int i = 0; i < LA; i++) __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LB; i++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // operand addresses: lane (row = lane & 31, k-half = lane >> 5) reads, per k-step s and plane p, unit (2 s + h) 3 + p
+    const int frow = lane & 31, fh = lane >> 5, rot = (frow / PER) % G;
+    int offA[BK / 16][3], offB[BK / 16][3];
+#pragma unroll
+    for (int s = 0; s < BK / 16; s++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int c = ((2 * s + fh) * 3 + p - rot + U) % U;
+            offA[s][p] = ((wm * WTM + frow) * U + c) * 16;
+            offB[s][p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
+        }
+
+    const int nk = g.K / BK;
+    issue(0, 0);
+    if (NS == 3 && nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt has landed (this wave's DMAs; the barrier extends that to the workgroup) and every wave is done with
+        // stage kt-1, whose buffer the next issue overwrites
+        if (NS == 3) {
+            if (kt + 1 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+        } else {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        }
+        const char* sb = smem + (NS == 3 ? kt % 3 : kt & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < BK / 16; s++) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[s][p] + i * 32 * U * 16);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[s][p] + j * 32 * U * 16);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    gemm_epilogue<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
+}
+
+// fp32 [M, ldx] -> bf3 [M][K/8][3][8]: one thread per group of 8 consecutive k (32 B in, 48 contiguous bytes out)
+__global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8) {
+    const long total = M * K8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / K8;
+        const int kg = (int)(i - row * K8);
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + row * ldx + kg * 8);
+        bf3_store8(y + row * ((size_t)K8 * 48), kg * 8, src[0], src[1]);
+    }
+}
+
+struct Bf3Tile { int bm, bn, occ; double eff; };
+// main-loop efficiencies measured on MI355X (tools/gemm_bf3_lab.hip, 18432-row ViT-L shapes): 256x128x32 8 waves
+// ~190, 128x128x16 (two workgroups per CU) ~175, 64x64x32 ~140 TFLOP/s fp32-equivalent
+static const Bf3Tile kTiles[3] = {{256, 128, 1, 1.0}, {128, 128, 2, 0.92}, {64, 64, 2, 0.72}};
+
+static int choose_bf3_tile(int M, int N, int groups) {
+    if (const char* f = getenv("A3R_BF3_TILE")) {      // developer override: 0 | 1 | 2
+        const int t = atoi(f);
+        if (t >= 0 && t < 3) return t;
+    }
+    int best_t = 0;
+    double best = 1e300;
+    for (int t = 0; t < 3; t++) {
+        const long n = (long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn) * groups;
+        const long slots = 256L * kTiles[t].occ;
+        const double cost = (double)((n + slots - 1) / slots) * kTiles[t].bm * kTiles[t].bn * kTiles[t].occ / kTiles[t].eff;
+        if (cost < best * 0.999) { best = cost; best_t = t; }
+    }
+    return best_t;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, bool FULL>
+static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
+    auto kern = gemm_bf3_kernel<BM, BN, BK, WM, WN, NS, FULL>;
+    constexpr int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(WM * WN * 64), lds, st, g);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+static int launch_bf3(GemmArgs& g, hipStream_t st) {
+    const int t = choose_bf3_tile(g.M, g.N, g.groups);
+    const int bm = kTiles[t].bm, bn = kTiles[t].bn;
+    g.tiles_m = (g.M + bm - 1) / bm;
+    g.tiles_n = (g.N + bn - 1) / bn;
+    g.tiles_per_group = g.tiles_m * g.tiles_n;
+    const bool full = g.M % bm == 0 && g.N % bn == 0;
+    ProfScope prof(PK_LINEAR, 2.0 * g.M * g.N * g.K * g.groups, st);
+    if (t == 0) return full ? launch_bf3_variant<256, 128, 32, 4, 2, 2, true>(g, st) : launch_bf3_variant<256, 128, 32, 4, 2, 2, false>(g, st);
+    if (t == 1) return full ? launch_bf3_variant<128, 128, 16, 2, 2, 3, true>(g, st) : launch_bf3_variant<128, 128, 16, 2, 2, 3, false>(g, st);
+    return full ? launch_bf3_variant<64, 64, 32, 2, 2, 3, true>(g, st) : launch_bf3_variant<64, 64, 32, 2, 2, 3, false>(g, st);
+}
+
+}  // namespace a3r
+using namespace a3r;
+
+extern "C" size_t a3r_bf3_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)rows * K * 6 : 0; }
+
+extern "C" int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream) {
+    A3R_CHECK_ARG(x && y, "a3r_split_bf3: null pointer");
+    A3R_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0, "a3r_split_bf3: K (%d) must be a positive multiple of 8 (M=%ld)", K, M);
+    A3R_CHECK_ARG(ldx >= K && ldx % 4 == 0, "a3r_split_bf3: bad leading dimension %d", ldx);
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "a3r_split_bf3: pointers must be 16-byte aligned");
+    const long total = M * (K / 8);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PK_ELEMENTWISE, 10.0 * M * K, st);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(split_bf3_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, st, x, ldx,
+                       static_cast<char*>(y), M, K / 8);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int ldc, int M, int N, int K,
+                                      const a3r_epilogue* epi, void* stream) {
+    A3R_CHECK_ARG(groups && n_groups >= 1 && n_groups <= 4, "a3r_linear_bf3_grouped: 1..4 groups required");
+    A3R_CHECK_ARG(M > 0 && N > 0 && K > 0, "a3r_linear_bf3: M, N, K must be positive (got %d, %d, %d)", M, N, K);
+    A3R_CHECK_ARG(K % 32 == 0, "a3r_linear_bf3: K (%d) must be a multiple of 32", K);
+    A3R_CHECK_ARG(ldc >= 1, "a3r_linear_bf3: bad leading dimension ldc=%d", ldc);
+    if (int rc = check_epilogue(epi, M, N, "a3r_linear_bf3")) return rc;
+    GemmArgs g = {};
+    if (epi) g.epi = *epi;
+    A3R_CHECK_ARG(!g.epi.relu_a, "a3r_linear_bf3: relu_a is only available on a3r_conv3x3");
+    for (int i = 0; i < n_groups; i++) {
+        g.grp[i] = {static_cast<const float*>(groups[i].x3), static_cast<const float*>(groups[i].w3), groups[i].y, groups[i].bias,
+                    groups[i].resid, groups[i].resid2};
+        if (int rc = check_group(g.grp[i], g.epi.epi, "a3r_linear_bf3")) return rc;
+    }
+    g.groups = n_groups;
+    g.lda = K; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    if (g.epi.epi != A3R_EPI_PIXSHUF) A3R_CHECK_ARG(ldc >= N, "a3r_linear_bf3: ldc (%d) < N (%d)", ldc, N);
+    return launch_bf3(g, as_stream(stream));
+}
+
+extern "C" int a3r_linear_bf3(const void* x3, const void* w3, float* y, int ldc, int M, int N, int K, const a3r_epilogue* epi,
+                              void* stream) {
+    a3r_group_ptrs_bf3 p = {x3, w3, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr};
+    return a3r_linear_bf3_grouped(&p, 1, ldc, M, N, K, epi, stream);
+}

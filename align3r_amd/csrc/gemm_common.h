@@ -1,0 +1,107 @@
+// Pieces shared by the MFMA GEMM kernels of liba3r (gemm.hip: exact-fp32 MFMA; gemm_bf3.hip: split-bf16 MFMA):
+// launch arguments, the fused epilogue (bias / GELU / ReLU / residuals / RoPE-2D / pixel-shuffle) and argument checks.
+#pragma once
+#include "common.h"
+
+namespace a3r {
+
+struct GroupPtrs {
+    const float* A;
+    const float* Wt;        // [N, K]
+    float* C;
+    const float* bias;
+    const float* resid;
+    const float* resid2;
+};
+
+struct GemmArgs {
+    GroupPtrs grp[4];
+    int groups, tiles_per_group;
+    int lda, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    a3r_epilogue epi;       // pointers inside are ignored (taken from grp[]) except the rope tables
+    // implicit conv (AMODE 1): A = x [B, H, W, Cin]
+    int cH, cW, cCin, cHo, cWo, cStride;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// Epilogue over the 32x32 MFMA accumulators of one wave: acc[i][j] covers rows m0 + wrow0 + 32 i .. and columns
+// n0 + wcol0 + 32 j ..; element e of a lane sits at row (e&3) + 8 (e>>2) + 4 (lane>>5), column lane&31.
+template <int TM, int TN, bool FULL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const GroupPtrs& P, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wrow0, int wcol0, int lane) {
+    const a3r_epilogue& ep = g.epi;
+    const int half = lane >> 5, lcol = lane & 31;
+    const int epi = ep.epi;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int colbase = n0 + wcol0 + j * 32;
+        const int col = colbase + lcol;
+        const bool col_ok = FULL || col < g.N;
+        const float bias = (P.bias && col_ok) ? P.bias[epi == A3R_EPI_PIXSHUF ? col % ep.ps_cout : col] : 0.f;
+        const bool do_rope = epi == A3R_EPI_ROPE && colbase < ep.rope_cols;   // wave-uniform (rope_cols % 64 == 0)
+        const bool rope_x = (colbase & 32) != 0;                               // second half of the head rotates with x
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                float v = acc[i][j][e] + bias;
+                if (do_rope) {
+                    // pairs (d, d+16) inside each 32-wide half of the head (RoPE2D pos_embed.py:130-157)
+                    const float other = __shfl_xor(v, 16);
+                    const int tok = row % ep.tokens_per_image;
+                    const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
+                    const int p = rope_x ? px : py;
+                    const float c = ep.rope_cos[p * 16 + (lcol & 15)], s = ep.rope_sin[p * 16 + (lcol & 15)];
+                    v = (lcol & 16) ? v * c + other * s : v * c - other * s;
+                }
+                if ((FULL || row < g.M) && col_ok) {
+                    if (epi == A3R_EPI_GELU) v = gelu_erf(v);
+                    else if (epi == A3R_EPI_RELU) v = fmaxf(v, 0.f);
+                    else if (epi == A3R_EPI_RESID) v = P.resid[(size_t)row * g.ldc + col] + v;
+                    else if (epi == A3R_EPI_RESID2) v = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v;
+                    if (epi == A3R_EPI_PIXSHUF) {
+                        const int s = ep.ps_s, hw = ep.ps_h * ep.ps_w;
+                        const int b = row / hw, rem = row - b * hw;
+                        const int y = rem / ep.ps_w, x = rem - y * ep.ps_w;
+                        const int tap = col / ep.ps_cout, co = col - tap * ep.ps_cout;
+                        const int dy = tap / s, dx = tap - dy * s;
+                        const size_t opix = ((size_t)b * ep.ps_h * s + (y * s + dy)) * (ep.ps_w * s) + (x * s + dx);
+                        P.C[opix * ep.ps_cout + co] = v;
+                    } else {
+                        P.C[(size_t)row * g.ldc + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who) {
+    if (!e) return A3R_OK;
+    A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_PIXSHUF, "%s: unknown epilogue %d", who, e->epi);
+    if (e->epi == A3R_EPI_ROPE)
+        A3R_CHECK_ARG(e->rope_cols % 64 == 0 && e->rope_cols <= N && e->tokens_per_image > 0 && e->grid_w > 0 &&
+                          e->tokens_per_image % e->grid_w == 0 && e->rope_cos && e->rope_sin,
+                      "%s: bad ROPE epilogue (rope_cols=%d tokens=%d grid_w=%d)", who, e->rope_cols,
+                      e->tokens_per_image, e->grid_w);
+    if (e->epi == A3R_EPI_PIXSHUF)
+        A3R_CHECK_ARG(e->ps_s > 0 && e->ps_cout > 0 && N == e->ps_s * e->ps_s * e->ps_cout && e->ps_h > 0 && e->ps_w > 0 &&
+                          M % (e->ps_h * e->ps_w) == 0,
+                      "%s: bad PIXSHUF epilogue", who);
+    return A3R_OK;
+}
+
+static inline int check_group(const GroupPtrs& p, int epi, const char* who) {
+    A3R_CHECK_ARG(p.A && p.Wt && p.C, "%s: null pointer", who);
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.Wt)) & 15) == 0,
+                  "%s: x and w must be 16-byte aligned", who);
+    if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) A3R_CHECK_ARG(p.resid, "%s: RESID epilogue without resid", who);
+    if (epi == A3R_EPI_RESID2) A3R_CHECK_ARG(p.resid2, "%s: RESID2 epilogue without resid2", who);
+    return A3R_OK;
+}
+
+}  // namespace a3r

@@ -112,6 +112,69 @@ def linear_grouped(xs, ws, biases, epi=_lib.EPI_NONE, resids=None, **kw):
     return outs
 
 
+class Bf3:
+    """An fp32 matrix [rows, K] in bf3 form (three exact bf16 planes, include/a3r.h): uint8 storage + logical shape."""
+
+    def __init__(self, data: torch.Tensor, rows: int, K: int):
+        self.data, self.rows, self.K = data, rows, K
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def planes(self):
+        """-> float32 [3, rows, K]: the three planes (their sum is the original matrix exactly)."""
+        u = self.data.view(torch.int16).view(self.rows, self.K // 8, 3, 8).to(torch.int32) << 16
+        return u.view(torch.float32).permute(2, 0, 1, 3).reshape(3, self.rows, self.K)
+
+
+def split_bf3(x) -> Bf3:
+    """fp32 x [..., K] -> bf3 (a3r_split_bf3)."""
+    _req(x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K
+    y = torch.empty(M * K * 6, device=x.device, dtype=torch.uint8)
+    check(_lib.load().a3r_split_bf3(ptr(x), K, ptr(y), M, K, stream_ptr()), "split_bf3")
+    return Bf3(y, M, K)
+
+
+def layernorm_bf3(x, w, b, eps=1e-6) -> Bf3:
+    """nn.LayerNorm over the last dim with the output written in bf3 form (a3r_layernorm_bf3)."""
+    _req(x, "x")
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty(M * D * 6, device=x.device, dtype=torch.uint8)
+    check(_lib.load().a3r_layernorm_bf3(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(y), M, D, eps, stream_ptr()), "layernorm_bf3")
+    return Bf3(y, M, D)
+
+
+def linear_bf3(x3: Bf3, w3: Bf3, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
+    """nn.Linear on the bf16 matrix cores with fp32 accuracy: x3 [M, K], w3 [N, K] in bf3 form (a3r_linear_bf3)."""
+    M, K, N = x3.rows, x3.K, w3.rows
+    if w3.K != K:
+        raise RuntimeError(f"linear_bf3: K mismatch ({K} vs {w3.K})")
+    if out is None:
+        out = torch.empty((M, N), device=x3.data.device, dtype=torch.float32)
+    e = make_epilogue(epi, bias, **kw)
+    check(_lib.load().a3r_linear_bf3(x3.data_ptr(), w3.data_ptr(), ptr(out), out.shape[-1] if epi != _lib.EPI_PIXSHUF else e.ps_cout,
+                                     M, N, K, C.byref(e), stream_ptr()), "linear_bf3")
+    return out
+
+
+def linear_bf3_grouped(x3s, w3s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
+    """Several same-shape bf3 nn.Linear problems in one launch (a3r_linear_bf3_grouped)."""
+    G = len(x3s)
+    M, K, N = x3s[0].rows, x3s[0].K, w3s[0].rows
+    outs = [torch.empty((M, N), device=x3s[0].data.device, dtype=torch.float32) for _ in range(G)]
+    arr = (_lib.GroupPtrs * G)()          # same field layout as a3r_group_ptrs_bf3
+    for i in range(G):
+        arr[i].x, arr[i].w, arr[i].y = x3s[i].data_ptr(), w3s[i].data_ptr(), outs[i].data_ptr()
+        arr[i].bias = None if biases is None else biases[i].data_ptr()
+        arr[i].resid = None if resids is None else resids[i].data_ptr()
+    e = make_epilogue(epi, **kw)
+    check(_lib.load().a3r_linear_bf3_grouped(arr, G, N, M, N, K, C.byref(e), stream_ptr()), "linear_bf3_grouped")
+    return outs
+
+
 def pack_conv3x3(w):
     Cout, Cin = w.shape[:2]
     wp = torch.empty((Cout, 3, 3, Cin), device=w.device, dtype=torch.float32)

@@ -113,6 +113,31 @@ typedef struct {
 int a3r_linear_grouped(const a3r_group_ptrs* groups, int n_groups, int lda, int ldc, int M, int N, int K,
                        const a3r_epilogue* epi, void* stream);
 
+/* ---- the same nn.Linear on the bf16 matrix cores, fp32-accurate ("bf3" operands)
+ * An fp32 matrix X [R, K] (K % 8 == 0) in bf3 form is three bf16 planes with X = X0 + X1 + X2 exactly, laid out
+ * [R][K/8][3][8] bf16 (6 K bytes per row, a3r_bf3_bytes).  a3r_linear_bf3 evaluates the six bf16 x bf16 plane
+ * products whose magnitude reaches fp32 precision (each exact in the fp32 accumulator; the dropped terms are
+ * <= 2^-23 |x w| per product), so y matches a3r_linear to fp32 rounding while running on the 16x faster bf16 MFMA
+ * pipes.  Replaces the same call sites as a3r_linear (blocks.py:58-169); epilogues as above. K % 32 == 0. */
+size_t a3r_bf3_bytes(long rows, int K);
+/* fp32 x [M, ldx] (first K columns) -> bf3 y [M][K/8][3][8] */
+int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream);
+/* nn.LayerNorm (as a3r_layernorm) writing its output directly in bf3 form (D % 8 == 0): the producer of every
+ * transformer GEMM input (blocks.py:127-130,186-190), fused so the fp32 normalised rows never reach HBM. */
+int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps, void* stream);
+int a3r_linear_bf3(const void* x3, const void* w3, float* y, int ldc, int M, int N, int K, const a3r_epilogue* epi,
+                   void* stream);
+typedef struct {
+    const void* x3;       /* bf3 [M, K] */
+    const void* w3;       /* bf3 [N, K] */
+    float* y;
+    const float* bias;
+    const float* resid;
+    const float* resid2;
+} a3r_group_ptrs_bf3;
+int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int ldc, int M, int N, int K,
+                           const a3r_epilogue* epi, void* stream);
+
 /* nn.Conv2d(k=3, padding=1, stride in {1,2}) on channels-last x [B, H, W, Cin] with PACKED weights
  * wp [Cout, 3, 3, Cin] (a3r_pack_conv3x3 from the checkpoint layout [Cout, Cin, 3, 3]); Cin % 32 == 0.
  * y [B, Ho, Wo, Cout].  Implicit GEMM on the same MFMA core.  (dpt_block.py:33-68,93-111,323-329,402-405) */

@@ -1,0 +1,110 @@
+"""GPU parity of the bf3 (split-bf16, fp32-accurate) nn.Linear path through the C ABI.
+
+The reference computes these projections with fp32 nn.Linear (croco/models/blocks.py:58-169).  The bf3 kernels
+evaluate the same fp32 products on the bf16 matrix cores from an exact three-plane split of both operands; the tests
+pin (i) that the split is exact, (ii) that the GEMM error against float64 is not larger than the exact-fp32 MFMA
+kernel's, and (iii) the fused epilogues / ragged shapes / grouped launches against a float64 torch reference.
+Tolerance: 2e-5 relative (same as the fp32 operator tests).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from align3r_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("M,K", [(7, 64), (300, 768), (1000, 1024)])
+def test_split_is_exact(ops, M, K):
+    x = rnd(M, K, seed=1, scale=3.0)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-30, 3.0e38, 1.17549435e-38, 0.1], device="cuda")
+    p = ops.split_bf3(x).planes()
+    # bf16 planes: low 16 bits clear by construction; their fp32 sum (largest first) reproduces x bit for bit
+    back = (p[0] + p[1]) + p[2]
+    assert torch.equal(back, x)
+    assert float((p[1].abs() > p[0].abs() * 2.0 ** -7 + 1e-38).sum()) == 0     # |x1| <= ulp_bf16(x0)/2
+
+
+@pytest.mark.parametrize("M,D", [(10, 1024), (333, 768), (5, 128), (64, 256), (9, 64)])
+def test_layernorm_bf3_equals_layernorm_then_split(ops, M, D):
+    x, w, b = rnd(M, D, seed=1, scale=3.0) + 0.5, rnd(D, seed=2), rnd(D, seed=3)
+    y3 = ops.layernorm_bf3(x, w, b)
+    want = ops.split_bf3(ops.layernorm(x, w, b))
+    assert torch.equal(y3.data, want.data)
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1000, 384, 128), (768, 1024, 1024), (130, 64, 32)])
+def test_linear_bf3_every_tile_shape(ops, monkeypatch, tile, M, N, K):
+    from align3r_amd import _lib
+    monkeypatch.setenv("A3R_BF3_TILE", tile)
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    x3, w3 = ops.split_bf3(x), ops.split_bf3(w)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert rel_err(cpu(ops.linear_bf3(x3, w3, b)), cpu(ref)) < TOL
+    assert rel_err(cpu(ops.linear_bf3(x3, w3, b, epi=_lib.EPI_GELU)), cpu(torch.nn.functional.gelu(ref))) < TOL
+    r = rnd(M, N, seed=4)
+    assert rel_err(cpu(ops.linear_bf3(x3, w3, b, epi=_lib.EPI_RESID, resid=r)), cpu(ref + r.double())) < TOL
+    if N % 64 == 0 and M % 5 == 0:
+        cos, sin = ops.rope_tables(x.device)
+        y = ops.linear_bf3(x3, w3, b, epi=_lib.EPI_ROPE, rope=(N, 5, 5, cos, sin))
+        want = ops.linear(x, w, b, epi=_lib.EPI_ROPE, rope=(N, 5, 5, cos, sin))
+        assert rel_err(cpu(y), cpu(want)) < TOL
+
+
+def test_linear_bf3_error_not_larger_than_fp32_mfma(ops):
+    """|err| / sum|x||w| against float64 for K = 4096: the bf3 GEMM is as accurate as the exact-fp32 MFMA GEMM."""
+    M, N, K = 512, 512, 4096
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    ref = x.double() @ w.double().T
+    mag = x.double().abs() @ w.double().abs().T
+    e_bf3 = float(((ops.linear_bf3(ops.split_bf3(x), ops.split_bf3(w)).double() - ref).abs() / mag).max())
+    e_f32 = float(((ops.linear(x, w).double() - ref).abs() / mag).max())
+    assert e_bf3 < 4e-7
+    assert e_bf3 <= 1.5 * e_f32 + 1e-8, (e_bf3, e_f32)
+
+
+def test_linear_bf3_grouped_and_determinism(ops):
+    from align3r_amd import _lib
+    M, N, K = 384, 192, 64
+    xs = [rnd(M, K, seed=i) for i in range(2)]
+    ws = [rnd(N, K, seed=10 + i, scale=K ** -0.5) for i in range(2)]
+    bs = [rnd(N, seed=20 + i) for i in range(2)]
+    rs = [rnd(M, N, seed=30 + i) for i in range(2)]
+    x3s, w3s = [ops.split_bf3(x) for x in xs], [ops.split_bf3(w) for w in ws]
+    outs = ops.linear_bf3_grouped(x3s, w3s, bs, epi=_lib.EPI_RESID, resids=rs)
+    again = ops.linear_bf3_grouped(x3s, w3s, bs, epi=_lib.EPI_RESID, resids=rs)
+    for i in range(2):
+        ref = torch.nn.functional.linear(xs[i].double(), ws[i].double(), bs[i].double()) + rs[i].double()
+        assert rel_err(cpu(outs[i]), cpu(ref)) < TOL
+        assert torch.equal(outs[i], again[i])
+
+
+def test_linear_bf3_argument_checks(ops):
+    x3, w3 = ops.split_bf3(rnd(64, 48, seed=1)), ops.split_bf3(rnd(64, 48, seed=2))
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.linear_bf3(x3, w3)
+    with pytest.raises(RuntimeError, match="K mismatch"):
+        ops.linear_bf3(ops.split_bf3(rnd(64, 64, seed=1)), w3)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        ops.split_bf3(rnd(4, 12, seed=1))

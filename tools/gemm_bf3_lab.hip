@@ -1,0 +1,222 @@
+// Developer lab (not part of the product): fp32-accurate GEMM on the bf16 matrix cores, both operands PRE-SPLIT into
+// three bf16 planes ("bf3": [rows][K/8][3][8] bf16, x = x0+x1+x2 exactly), staged global->LDS by LDS-DMA (glds).
+//   C = sum over (p,q), p+q<=2 of A_p * W_q^T   (six exact-product MFMA passes, fp32 accumulate)
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bf3_lab.hip -o build/gemm_bf3_lab ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <cmath>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS image of one operand stage: rows of U = 3*BK/8 16-byte units, unpadded, unit c of row r stored at unit
+// (c - rot(r)) mod U with rot(r) = (r / (16/G)) % G, G = BK/8: conflict-free ds_read_b128 for the 32x32x16 operand.
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Wp, float* __restrict__ C,
+                                                          int M, int N, int K) {
+    constexpr int NT = WM * WN * 64, KG = BK / 8, U = 3 * KG, G = KG, PER = 16 / G;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int SA = BM * U, SB = BN * U, LA = SA / NT, LB = SB / NT;
+    static_assert(SA % NT == 0 && SB % NT == 0, "stage slots must divide by threads");
+    constexpr int STAGE = (SA + SB) * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = N / BN, tiles_m = M / BM, nwg = tiles_m * tiles_n;
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tile_m = wgid / tiles_n, tile_n = wgid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const size_t pitch = (size_t)K * 6;                // bytes per bf3 row
+    const char* srcA[LA];
+    const char* srcB[LB];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
+        srcA[i] = reinterpret_cast<const char*>(Ap) + (size_t)(m0 + r) * pitch + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; i++) {
+        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
+        srcB[i] = reinterpret_cast<const char*>(Wp) + (size_t)(n0 + r) * pitch + c * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE + wave * 1024;
+        const size_t koff = (size_t)kt * (KG * 48);
+#pragma unroll
+        for (int i = 0; i < LA; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + NT * 16 * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LB; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    const int frow = lane & 31, fh = lane >> 5, rot = (frow / PER) % G;
+    int offA[BK / 16][3], offB[BK / 16][3];
+#pragma unroll
+    for (int s = 0; s < BK / 16; s++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int c = ((2 * s + fh) * 3 + p - rot + U) % U;
+            offA[s][p] = ((wm * (BM / WM) + frow) * U + c) * 16;
+            offB[s][p] = SA * 16 + ((wn * (BN / WN) + frow) * U + c) * 16;
+        }
+    const int nk = K / BK;
+    constexpr int LPS = LA + LB;                        // glds per thread per stage
+    issue(0, 0);
+    if (NS == 3 && nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; kt++) {
+        if (NS == 3) {
+            if (kt + 1 < nk) wait_vm<LPS>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+        } else {
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        }
+        const char* sb = smem + (NS == 3 ? kt % 3 : kt & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < BK / 16; s++) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[s][p] + i * 32 * U * 16);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[s][p] + j * 32 * U * 16);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (NS == 2) {                                  // all waves done reading this buffer's partner before it is refilled
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    const int half = lane >> 5, lcol = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int col = n0 + wn * (BN / WN) + j * 32 + lcol;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                C[(size_t)row * N + col] = acc[i][j][e];
+            }
+    }
+}
+
+static uint16_t bf16_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16;
+    return (uint16_t)u;
+}
+static float bf16_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static void split_rows(const std::vector<float>& X, std::vector<uint16_t>& P, int R, int K) {
+    P.resize((size_t)R * K * 3);
+    for (int n = 0; n < R; n++)
+        for (int k = 0; k < K; k++) {
+            float x = X[(size_t)n * K + k];
+            uint16_t p0 = bf16_rne(x); float r1 = x - bf16_f(p0);
+            uint16_t p1 = bf16_rne(r1); float r2 = r1 - bf16_f(p1);
+            uint16_t p2 = bf16_rne(r2);
+            size_t base = ((size_t)n * (K / 8) + k / 8) * 24 + (k % 8);
+            P[base] = p0; P[base + 8] = p1; P[base + 16] = p2;
+        }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+double run(const char* name, const uint16_t* Ap, const uint16_t* Wp, float* C, int M, int N, int K, int iters) {
+    auto kern = gemm_bf3<BM, BN, BK, WM, WN, NS>;
+    const int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
+    if (M % BM || N % BN || K % BK) { printf("%-34s skipped (shape)\n", name); return 0; }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int blocks = (M / BM) * (N / BN);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(WM * WN * 64), lds, 0, Ap, Wp, C, M, N, K);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(WM * WN * 64), lds, 0, Ap, Wp, C, M, N, K);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-34s M=%5d N=%5d K=%5d blocks=%5d lds=%6d  %8.1f us  %7.2f TF(fp32-equiv)\n", name, M, N, K, blocks, lds, us, tf);
+    return us;
+}
+
+int main(int argc, char** argv) {
+    const int only_shape = argc > 1 ? atoi(argv[1]) : -1;
+    const unsigned mask = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 0) : 0xffffffffu;
+    int shape_idx = -1;
+    const int shapes[][3] = {{4096, 4096, 4096}, {18432, 4096, 1024}, {18432, 3072, 1024}, {18432, 1024, 1024}, {18432, 1024, 4096},
+                             {18432, 768, 768}, {18432, 768, 3072}};
+    for (auto& sh : shapes) {
+        const int M = sh[0], N = sh[1], K = sh[2];
+        shape_idx++;
+        if (only_shape >= 0 && shape_idx != only_shape) continue;
+        std::vector<float> hA((size_t)M * K), hW((size_t)N * K);
+        uint64_t s = 88172645463325252ull;
+        auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0); };
+        for (auto& v : hA) v = rnd();
+        for (auto& v : hW) v = rnd() * 0.05f;
+        std::vector<uint16_t> hAp, hWp;
+        split_rows(hA, hAp, M, K); split_rows(hW, hWp, N, K);
+        uint16_t *Ap, *Wp; float* C;
+        CK(hipMalloc(&Ap, hAp.size() * 2)); CK(hipMalloc(&Wp, hWp.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4));
+        CK(hipMemcpy(Ap, hAp.data(), hAp.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(Wp, hWp.data(), hWp.size() * 2, hipMemcpyHostToDevice));
+        const int it = 20;
+        auto check = [&](const char* what) {
+            std::vector<float> hC((size_t)8 * N);
+            CK(hipMemcpy(hC.data(), C + (size_t)(M - 8) * N, hC.size() * 4, hipMemcpyDeviceToHost));
+            double maxrel = 0;
+            for (int rr = 0; rr < 8; rr++)
+                for (int n = 0; n < N; n += 7) {
+                    double ref = 0, mag = 0;
+                    for (int k = 0; k < K; k++) { double p = (double)hA[(size_t)(M - 8 + rr) * K + k] * (double)hW[(size_t)n * K + k]; ref += p; mag += fabs(p); }
+                    double e = fabs((double)hC[(size_t)rr * N + n] - ref) / mag;
+                    if (e > maxrel) maxrel = e;
+                }
+            printf("   %s: max |err| / sum|a||b| = %.3e\n", what, maxrel);
+            CK(hipMemset(C, 0, (size_t)M * N * 4));
+        };
+        if (mask & 1u) run<128, 128, 32, 2, 2, 2>("128x128x32 4w 2-stage", Ap, Wp, C, M, N, K, it); if (mask & 1u) check("2-stage");
+        if (mask & 2u) run<128, 128, 32, 2, 2, 3>("128x128x32 4w 3-stage", Ap, Wp, C, M, N, K, it); if (mask & 2u) check("3-stage");
+        if (mask & 4u) run<128, 128, 16, 2, 2, 3>("128x128x16 4w 3-stage", Ap, Wp, C, M, N, K, it); if (mask & 4u) check("bk16 3-stage");
+        if (mask & 8u) run<256, 128, 32, 2, 2, 2>("256x128x32 4w(128x64) 2-stage", Ap, Wp, C, M, N, K, it); if (mask & 8u) check("256x128 4w 2-stage");
+        if (mask & 16u) run<256, 128, 32, 4, 2, 2>("256x128x32 8w 2-stage", Ap, Wp, C, M, N, K, it); if (mask & 16u) check("256x128 2-stage");
+        if (mask & 32u) run<256, 256, 16, 4, 2, 3>("256x256x16 8w 3-stage", Ap, Wp, C, M, N, K, it); if (mask & 32u) check("256x256 3-stage");
+        if (mask & 64u) run<128, 64, 32, 2, 2, 3>("128x64x32 4w 3-stage", Ap, Wp, C, M, N, K, it);
+        if (mask & 128u) run<64, 64, 32, 2, 2, 3>("64x64x32 4w 3-stage", Ap, Wp, C, M, N, K, it);
+        CK(hipFree(Ap)); CK(hipFree(Wp)); CK(hipFree(C));
+    }
+    return 0;
+}
