@@ -194,7 +194,7 @@ static int launch_bf3(GemmArgs& g, hipStream_t st) {
     g.tiles_n = (g.N + bn - 1) / bn;
     g.tiles_per_group = g.tiles_m * g.tiles_n;
     const bool full = g.M % bm == 0 && g.N % bn == 0;
-    ProfScope prof(PK_LINEAR, 2.0 * g.M * g.N * g.K * g.groups, st);
+    ProfScope prof(PK_LINEAR_BF3, 2.0 * g.M * g.N * g.K * g.groups, st);
     if (t == 0) return full ? launch_bf3_variant<256, 128, 32, 4, 2, 2, true>(g, st) : launch_bf3_variant<256, 128, 32, 4, 2, 2, false>(g, st);
     if (t == 1) return full ? launch_bf3_variant<128, 128, 16, 2, 2, 3, true>(g, st) : launch_bf3_variant<128, 128, 16, 2, 2, 3, false>(g, st);
     return full ? launch_bf3_variant<64, 64, 32, 2, 2, 3, true>(g, st) : launch_bf3_variant<64, 64, 32, 2, 2, 3, false>(g, st);
@@ -212,7 +212,7 @@ extern "C" int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, vo
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "a3r_split_bf3: pointers must be 16-byte aligned");
     const long total = M * (K / 8);
     hipStream_t st = as_stream(stream);
-    ProfScope prof(PK_ELEMENTWISE, 10.0 * M * K, st);
+    ProfScope prof(PK_SPLIT, 10.0 * M * K, st);
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(split_bf3_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, st, x, ldx,
                        static_cast<char*>(y), M, K / 8);

@@ -60,6 +60,9 @@ struct a3r_model_s {
     const float *rope_cos = nullptr, *rope_sin = nullptr;
     std::vector<float> host_cos, host_sin;
     std::map<std::string, std::pair<const float*, size_t>> taps;
+    // nn.Linear weights also kept in bf3 form (gemm_bf3.hip) unless A3R_GEMM=f32: fp32 pointer -> bf3 twin in `packed`
+    bool use_bf3 = true;
+    std::map<const float*, const void*> w3;
     static constexpr int MAX_POS = 256;
 };
 
@@ -78,6 +81,7 @@ extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
     a3r_model_s* m = new (std::nothrow) a3r_model_s();
     A3R_CHECK_ARG(m, "out of host memory");
     m->cfg = *cfg;
+    if (const char* e = getenv("A3R_GEMM")) m->use_bf3 = std::string(e) != "f32";
     // sized here so that the host-side sizing pass (a3r_model_workspace_bytes) works before finalize
     m->enc.assign(cfg->enc_depth, BlockW());
     m->pc.assign(n_pc_blocks(*cfg), BlockW());
@@ -107,7 +111,8 @@ extern "C" int a3r_model_set_weight(a3r_model_t m, const char* name, const float
 
 // ------------------------------------------------------------------------------------------- packing plan
 namespace {
-struct PackItem { std::string name; int kind; int a, b, s; size_t off; };   // kind 0: conv3x3 [Cout=a,Cin=b]; 1: convT [Cin=a,Cout=b,s]; 2: kv-concat (D=a)
+// kind 0: conv3x3 [Cout=a,Cin=b]; 1: convT [Cin=a,Cout=b,s]; 2: kv-concat (D=a); 3: rope tables; 4: bf3 twin of the [a, b] nn.Linear weight `name`
+struct PackItem { std::string name; int kind; int a, b, s; size_t off; };
 
 std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
     const a3r_model_config& c = m->cfg;
@@ -139,6 +144,31 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
         }
     v.push_back({"rope", 3, 0, 0, 0, off});
     off = align_up(off + (size_t)2 * a3r_model_s::MAX_POS * 16 * 4, 256);
+    if (m->use_bf3) {
+        auto twin = [&](const std::string& n, int N, int K) {
+            v.push_back({n, 4, N, K, 0, off});
+            off = align_up(off + (size_t)N * K * 6, 256);
+        };
+        auto block = [&](const std::string& p, int Dm, bool cross) {
+            twin(p + ".attn.qkv.weight", 3 * Dm, Dm); twin(p + ".attn.proj.weight", Dm, Dm);
+            twin(p + ".mlp.fc1.weight", Dm * c.mlp_ratio, Dm); twin(p + ".mlp.fc2.weight", Dm, Dm * c.mlp_ratio);
+            if (cross) {
+                twin(p + ".cross_attn.projq.weight", Dm, Dm); twin(p + ".cross_attn.kv", 2 * Dm, Dm);
+                twin(p + ".cross_attn.proj.weight", Dm, Dm);
+            }
+        };
+        const int E = c.enc_embed_dim;
+        for (int i = 0; i < c.enc_depth; i++) block("enc_blocks." + std::to_string(i), E, false);
+        for (int i = 0; i < n_pc_blocks(c); i++) block("dec_blocks_pc." + std::to_string(i), D, false);
+        for (int i = 0; i < c.dec_depth; i++) {
+            block("dec_blocks." + std::to_string(i), D, true);
+            block("dec_blocks2." + std::to_string(i), D, true);
+        }
+        twin("patch_embed.proj.weight", E, 768);
+        twin("patch_embed_point_cloud.proj.weight", D, 768);
+        twin("decoder_embed.weight", D, E);
+        for (int i = 0; i <= n_pc_blocks(c); i++) twin("zero_convs." + std::to_string(i) + ".0.weight", D, D);
+    }
     *total = off;
     return v;
 }
@@ -206,6 +236,7 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
     // --- repack
     for (const PackItem& it : plan) {
         float* dst = reinterpret_cast<float*>(pk + it.off);
+        if (it.kind == 4) continue;      // after binding (shapes are validated there)
         if (it.kind == 0) {
             const float* src;
             NEED(it.name, &src, it.a, it.b, 3, 3);
@@ -293,6 +324,18 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
         H.h2w = packed_ptr[p + "head.2.weight"]; NEED(p + "head.2.bias", &H.h2b, L);
         NEED(p + "head.4.weight", &H.h4w, 4, L, 1, 1); NEED(p + "head.4.bias", &H.h4b, 4);
     }
+    // --- bf3 twins of the nn.Linear weights
+    m->w3.clear();
+    for (const PackItem& it : plan) {
+        if (it.kind != 4) continue;
+        const float* src = nullptr;
+        auto pit = packed_ptr.find(it.name);
+        if (pit != packed_ptr.end()) src = pit->second;                 // the concatenated cross-attention k/v projection
+        else src = m->w.at(it.name).p;                                   // bound (and shape-checked) above
+        void* dst = pk + it.off;
+        if (int rc = a3r_split_bf3(src, it.b, dst, it.a, it.b, stream)) return rc;
+        m->w3[src] = dst;
+    }
     m->finalized = true;
     return A3R_OK;
 }
@@ -328,9 +371,43 @@ struct Plan {
         e.epi = kind; e.bias = bias; e.resid = resid; e.resid2 = resid2;
         return e;
     }
-    void linear(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e) {
+    // ---- "GEMM input" (gin) buffers: [rows, K] fp32 in f32 mode, the bf3 form of it (1.5x the bytes, bf3.h) otherwise
+    bool bf3() const { return m->use_bf3; }
+    float* gin_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
+    float* gin_scratch(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : 0); }     // only needed for splitting
+    template <class T> T* gin_at(T* base, size_t rows, int K) const { return base + (bf3() ? rows * K * 3 / 2 : rows * K); }
+    // fp32 activation -> GEMM input: a split pass into `scratch` in bf3 mode, the array itself otherwise
+    const float* gin_from(const float* x, float* scratch, long M, int K) {
+        if (!bf3()) return x;
+        if (skip()) return scratch;
+        traced("split_bf3", (int)M, K);
+        rc = a3r_split_bf3(x, K, scratch, M, K, stream);
+        return scratch;
+    }
+    const void* twin(const float* w) {
+        auto it = m->w3.find(w);
+        if (it == m->w3.end()) {
+            set_error("a3r_model_forward: nn.Linear weight without a bf3 twin");
+            rc = A3R_ESTATE;
+            return nullptr;
+        }
+        return it->second;
+    }
+    // nn.Linear on a GEMM-input buffer (bf3 MFMA path unless A3R_GEMM=f32)
+    void linear(const float* xg, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e) {
         if (skip()) return;
         traced("linear", M, N, K);
+        if (bf3()) {
+            const void* w3 = twin(w);
+            if (w3) rc = a3r_linear_bf3(xg, w3, y, ldc, M, N, K, &e, stream);
+        } else {
+            rc = a3r_linear(xg, lda, w, y, ldc, M, N, K, &e, stream);
+        }
+    }
+    // nn.Linear / 1x1 conv on a plain fp32 activation (DPT adapters), exact-fp32 MFMA
+    void linear_f32(const float* x, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e) {
+        if (skip()) return;
+        traced("linear_f32", M, N, K);
         rc = a3r_linear(x, lda, w, y, ldc, M, N, K, &e, stream);
     }
     // the same-shape projection of both decoders (dec_blocks[i] on view 1, dec_blocks2[i] on view 2) in one launch
@@ -339,12 +416,25 @@ struct Plan {
                  const float* r1 = nullptr) {
         if (skip()) return;
         traced("linear2", M, N, K);
-        a3r_group_ptrs g[2] = {{x0, w0, y0, b0, r0, nullptr}, {x1, w1, y1, b1, r1, nullptr}};
-        rc = a3r_linear_grouped(g, 2, lda, ldc, M, N, K, &e, stream);
+        if (bf3()) {
+            const void *w30 = twin(w0), *w31 = twin(w1);
+            if (!w30 || !w31) return;
+            a3r_group_ptrs_bf3 g[2] = {{x0, w30, y0, b0, r0, nullptr}, {x1, w31, y1, b1, r1, nullptr}};
+            rc = a3r_linear_bf3_grouped(g, 2, ldc, M, N, K, &e, stream);
+        } else {
+            a3r_group_ptrs g[2] = {{x0, w0, y0, b0, r0, nullptr}, {x1, w1, y1, b1, r1, nullptr}};
+            rc = a3r_linear_grouped(g, 2, lda, ldc, M, N, K, &e, stream);
+        }
     }
-    void ln(const float* x, const float* w, const float* b, float* y, int M, int D) {
+    // LayerNorm whose output feeds a GEMM (written directly in bf3 form in bf3 mode)
+    void ln(const float* x, const float* w, const float* b, float* yg, int M, int D) {
         if (skip()) return;
         traced("layernorm", M, D);
+        rc = bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
+    }
+    void ln_f32(const float* x, const float* w, const float* b, float* y, int M, int D) {
+        if (skip()) return;
+        traced("layernorm_f32", M, D);
         rc = a3r_layernorm(x, w, b, y, M, D, 1e-6f, stream);
     }
     void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
@@ -370,19 +460,20 @@ struct Plan {
     }
 
     // Block.forward blocks.py:127-130 on x [M, D] in place (self-attention over images of ntok tokens)
-    void self_block(const BlockW& w, float* x, const float* resid_src, int M, int D, int H, int ntok, int gw, int hidden,
-                    float* xn, float* qkv, float* att, float* hid) {
+    // xn: gin [M, D]; att / hid: fp32; att3 / hid3: gin scratch of the same shapes
+    void self_block(const BlockW& w, float* x, const float* resid_src, int M, int D, int H, int ntok, int gw, float* xn,
+                    float* qkv, float* att, float* att3) {
         // x_out = resid_src + attn(LN1(resid_src)); then MLP in place on x
         ln(resid_src, w.n1w, w.n1b, xn, M, D);
         linear(xn, D, w.qkvw, qkv, 3 * D, M, 3 * D, D, rope_epi(w.qkvb, 2 * D, ntok, gw));
         attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, M / ntok, H, ntok, ntok);
-        linear(att, D, w.projw, x, D, M, D, D, epi(A3R_EPI_RESID, w.projb, resid_src));
-        (void)hidden; (void)hid;
+        linear(gin_from(att, att3, M, D), D, w.projw, x, D, M, D, D, epi(A3R_EPI_RESID, w.projb, resid_src));
     }
-    void mlp(const BlockW& w, const float* nw, const float* nb, float* x, int M, int D, int hidden, float* xn, float* hid) {
+    void mlp(const BlockW& w, const float* nw, const float* nb, float* x, int M, int D, int hidden, float* xn, float* hid,
+             float* hid3) {
         ln(x, nw, nb, xn, M, D);
         linear(xn, D, w.fc1w, hid, hidden, M, hidden, D, epi(A3R_EPI_GELU, w.fc1b));
-        linear(hid, hidden, w.fc2w, x, D, M, D, hidden, epi(A3R_EPI_RESID, w.fc2b, x));
+        linear(gin_from(hid, hid3, M, hidden), hidden, w.fc2w, x, D, M, D, hidden, epi(A3R_EPI_RESID, w.fc2b, x));
     }
 };
 
@@ -414,7 +505,7 @@ float* fusion(Plan& P, const FusionW& w, const float* x0, const float* x1, bool 
     float* u = ar.alloc((size_t)B * Hc * Wc * F);
     P.up(o, u, B, H, W, F, Hc, Wc);
     float* r = ar.alloc((size_t)B * Hc * Wc * F);
-    P.linear(u, F, w.ow, r, F, B * Hc * Wc, F, F, P.epi(A3R_EPI_NONE, w.ob));
+    P.linear_f32(u, F, w.ow, r, F, B * Hc * Wc, F, F, P.epi(A3R_EPI_NONE, w.ob));
     return r;
 }
 
@@ -435,21 +526,24 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         // ---------------- encoder only, B images (_encode_image model.py:151-163): per-frame features for caching.
         // The reference re-encodes a frame for every pair it appears in; the result does not depend on the pair.
         float* cols = ar.alloc((size_t)BN * 768);
+        float* cols3 = P.gin_scratch(BN, 768);
         float* x = ar.alloc((size_t)BN * E);
-        float* xn = ar.alloc((size_t)BN * E);
+        float* xn = P.gin_alloc(BN, E);
         float* qkv = ar.alloc((size_t)BN * 3 * E);
         float* att = ar.alloc((size_t)BN * E);
+        float* att3 = P.gin_scratch(BN, E);
         float* hid = ar.alloc((size_t)BN * E * c.mlp_ratio);
+        float* hid3 = P.gin_scratch(BN, E * c.mlp_ratio);
         if (!dry) {
             const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
             if ((P.rc = a3r_patchify(img1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
         }
-        P.linear(cols, 768, m->pe_w, x, E, BN, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
+        P.linear(P.gin_from(cols, cols3, BN, 768), 768, m->pe_w, x, E, BN, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
         for (int i = 0; i < c.enc_depth; i++) {
-            P.self_block(m->enc[i], x, x, BN, E, c.enc_num_heads, N, nw, E * c.mlp_ratio, xn, qkv, att, hid);
-            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, BN, E, E * c.mlp_ratio, xn, hid);
+            P.self_block(m->enc[i], x, x, BN, E, c.enc_num_heads, N, nw, xn, qkv, att, att3);
+            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, BN, E, E * c.mlp_ratio, xn, hid, hid3);
         }
-        P.ln(x, m->encn_w, m->encn_b, dry ? nullptr : feat_out, BN, E);
+        P.ln_f32(x, m->encn_w, m->encn_b, dry ? nullptr : feat_out, BN, E);
         if (peak) *peak = ar.peak;
         return P.rc;
     }
@@ -464,6 +558,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     if (phase == 2) {
         // cached per-frame features: gather the two views' rows into the [2*B*N, E] layout the decoder expects
         float* cols = ar.alloc((size_t)M2 * 768);
+        float* cols3 = P.gin_scratch(M2, 768);
         if (!dry) {
             const size_t bytes = (size_t)BN * E * sizeof(float);
             hipError_t e1 = hipMemcpyAsync(feat, feat1_in, bytes, hipMemcpyDeviceToDevice, as_stream(stream));
@@ -473,32 +568,35 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             if ((P.rc = a3r_patchify(pd1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
             if ((P.rc = a3r_patchify(pd2, cols + (size_t)BN * 768, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
         }
-        P.linear(cols, 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
+        P.linear(P.gin_from(cols, cols3, M2, 768), 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
     } else {
         float* cols = ar.alloc((size_t)M2 * 768);
+        float* cols3 = P.gin_scratch(M2, 768);
         float* x = ar.alloc((size_t)M2 * E);
-        float* xn = ar.alloc((size_t)M2 * E);
+        float* xn = P.gin_alloc(M2, E);
         float* qkv = ar.alloc((size_t)M2 * 3 * E);
         float* att = ar.alloc((size_t)M2 * E);
+        float* att3 = P.gin_scratch(M2, E);
         float* hid = ar.alloc((size_t)M2 * E * c.mlp_ratio);
+        float* hid3 = P.gin_scratch(M2, E * c.mlp_ratio);
         if (!dry) {
             const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
             if ((P.rc = a3r_patchify(img1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
             if ((P.rc = a3r_patchify(img2, cols + (size_t)BN * 768, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
         }
-        P.linear(cols, 768, m->pe_w, x, E, M2, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
+        P.linear(P.gin_from(cols, cols3, M2, 768), 768, m->pe_w, x, E, M2, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
         for (int i = 0; i < c.enc_depth; i++) {
-            P.self_block(m->enc[i], x, x, M2, E, c.enc_num_heads, N, nw, E * c.mlp_ratio, xn, qkv, att, hid);
-            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, M2, E, E * c.mlp_ratio, xn, hid);
+            P.self_block(m->enc[i], x, x, M2, E, c.enc_num_heads, N, nw, xn, qkv, att, att3);
+            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, M2, E, E * c.mlp_ratio, xn, hid, hid3);
         }
-        P.ln(x, m->encn_w, m->encn_b, feat, M2, E);
+        P.ln_f32(x, m->encn_w, m->encn_b, feat, M2, E);
         // point-map patch embedding (model.py:244-248); pred_depth is [B,H,W,3]: channel stride 1
         if (!dry) {
             const long sb = 3L * H * W, sc = 1, sy = 3L * W, sx = 3;
             if ((P.rc = a3r_patchify(pd1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
             if ((P.rc = a3r_patchify(pd2, cols + (size_t)BN * 768, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
         }
-        P.linear(cols, 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
+        P.linear(P.gin_from(cols, cols3, M2, 768), 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
     }
     ar.off = mark;
     // ---------------- decoder (model.py:201-233)
@@ -506,16 +604,22 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     const float *lvl_a = nullptr, *lvl_b = nullptr;
     {
         const int hidden = D * c.mlp_ratio;
-        float* xn = ar.alloc((size_t)M2 * D);
-        float* yn = ar.alloc((size_t)M2 * D);
+        float* xn = P.gin_alloc(M2, D);
+        float* yn = P.gin_alloc(M2, D);
         float* qkv = ar.alloc((size_t)M2 * 3 * D);
         float* qb = ar.alloc((size_t)M2 * D);
         float* kv = ar.alloc((size_t)M2 * 2 * D);
         float* att = ar.alloc((size_t)M2 * D);
+        float* att3 = P.gin_scratch(M2, D);
         float* hid = ar.alloc((size_t)M2 * hidden);
+        float* hid3 = P.gin_scratch(M2, hidden);
+        float* pc3 = P.gin_scratch(M2, D);
         float* cur = fbuf[0];
-        P.linear(feat, E, m->de_w, cur, D, M2, D, E, P.epi(A3R_EPI_NONE, m->de_b));
-        P.linear(pc, D, m->zc_w[0], cur, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[0], cur));
+        {
+            float* feat3 = P.gin_scratch(M2, E);
+            P.linear(P.gin_from(feat, feat3, M2, E), E, m->de_w, cur, D, M2, D, E, P.epi(A3R_EPI_NONE, m->de_b));
+        }
+        P.linear(P.gin_from(pc, pc3, M2, D), D, m->zc_w[0], cur, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[0], cur));
         int next_free = 1;
         const int npc = n_pc_blocks(c);
         for (int i = 0; i < c.dec_depth; i++) {
@@ -534,42 +638,53 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 const float *x0 = cur, *x1 = cur + S;
                 float *o0 = nxt, *o1 = nxt + S;
                 // x = x + attn(norm1(x))                                   blocks.py:187
+                float* xn1 = P.gin_at(xn, BN, D);                  // side 1 of the gin buffers
+                float* yn1 = P.gin_at(yn, BN, D);
                 P.ln(x0, w0.n1w, w0.n1b, xn, BN, D);
-                P.ln(x1, w1.n1w, w1.n1b, xn + S, BN, D);
-                P.linear2(xn, xn + S, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, qkv + 3 * S, 3 * D, BN, 3 * D, D,
+                P.ln(x1, w1.n1w, w1.n1b, xn1, BN, D);
+                P.linear2(xn, xn1, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, qkv + 3 * S, 3 * D, BN, 3 * D, D,
                           P.rope_epi(nullptr, 2 * D, N, nw));
                 P.attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, 2 * B, c.dec_num_heads, N, N);
-                P.linear2(att, att + S, D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
-                          P.epi(A3R_EPI_RESID, nullptr), x0, x1);
+                {
+                    const float* ag = P.gin_from(att, att3, M2, D);
+                    P.linear2(ag, P.gin_at(ag, BN, D), D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
+                              P.epi(A3R_EPI_RESID, nullptr), x0, x1);
+                }
                 // y_ = norm_y(y); x = x + cross_attn(norm2(x), y_, y_)     blocks.py:188-189
                 P.ln(x1, w0.nyw, w0.nyb, yn, BN, D);               // side 0 attends to view 2's tokens
-                P.ln(x0, w1.nyw, w1.nyb, yn + S, BN, D);
+                P.ln(x0, w1.nyw, w1.nyb, yn1, BN, D);
                 P.ln(o0, w0.n2w, w0.n2b, xn, BN, D);
-                P.ln(o1, w1.n2w, w1.n2b, xn + S, BN, D);
-                P.linear2(xn, xn + S, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, qb + S, D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
-                P.linear2(yn, yn + S, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, kv + 2 * S, 2 * D, BN, 2 * D, D,
+                P.ln(o1, w1.n2w, w1.n2b, xn1, BN, D);
+                P.linear2(xn, xn1, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, qb + S, D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
+                P.linear2(yn, yn1, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, kv + 2 * S, 2 * D, BN, 2 * D, D,
                           P.rope_epi(nullptr, D, N, nw));
                 P.attn(qb, D, kv, 2 * D, kv + D, 2 * D, att, D, 2 * B, c.dec_num_heads, N, N);
-                P.linear2(att, att + S, D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
-                          P.epi(A3R_EPI_RESID, nullptr), o0, o1);
+                {
+                    const float* ag = P.gin_from(att, att3, M2, D);
+                    P.linear2(ag, P.gin_at(ag, BN, D), D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
+                              P.epi(A3R_EPI_RESID, nullptr), o0, o1);
+                }
                 // x = x + mlp(norm3(x))                                    blocks.py:190
                 P.ln(o0, w0.n3w, w0.n3b, xn, BN, D);
-                P.ln(o1, w1.n3w, w1.n3b, xn + S, BN, D);
-                P.linear2(xn, xn + S, D, w0.fc1w, w1.fc1w, w0.fc1b, w1.fc1b, hid, hid + (size_t)BN * hidden, hidden, BN, hidden, D,
+                P.ln(o1, w1.n3w, w1.n3b, xn1, BN, D);
+                P.linear2(xn, xn1, D, w0.fc1w, w1.fc1w, w0.fc1b, w1.fc1b, hid, hid + (size_t)BN * hidden, hidden, BN, hidden, D,
                           P.epi(A3R_EPI_GELU, nullptr));
-                P.linear2(hid, hid + (size_t)BN * hidden, hidden, w0.fc2w, w1.fc2w, w0.fc2b, w1.fc2b, o0, o1, D, BN, D, hidden,
-                          P.epi(A3R_EPI_RESID, nullptr), o0, o1);
+                {
+                    const float* hg = P.gin_from(hid, hid3, M2, hidden);
+                    P.linear2(hg, P.gin_at(hg, BN, hidden), hidden, w0.fc2w, w1.fc2w, w0.fc2b, w1.fc2b, o0, o1, D, BN, D, hidden,
+                              P.epi(A3R_EPI_RESID, nullptr), o0, o1);
+                }
             }
             if (i < npc) {   // model.py:223-226
-                P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, hidden, xn, qkv, att, hid);
-                P.mlp(m->pc[i], m->pc[i].n2w, m->pc[i].n2b, pc, M2, D, hidden, xn, hid);
-                P.linear(pc, D, m->zc_w[i + 1], nxt, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[i + 1], nxt));
+                P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, xn, qkv, att, att3);
+                P.mlp(m->pc[i], m->pc[i].n2w, m->pc[i].n2b, pc, M2, D, hidden, xn, hid, hid3);
+                P.linear(P.gin_from(pc, pc3, M2, D), D, m->zc_w[i + 1], nxt, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[i + 1], nxt));
             }
             if (level == hook_a) lvl_a = nxt;
             if (level == hook_b) lvl_b = nxt;
             cur = nxt;
         }
-        P.ln(cur, m->decn_w, m->decn_b, dec_last, M2, D);   // model.py:231-232
+        P.ln_f32(cur, m->decn_w, m->decn_b, dec_last, M2, D);   // model.py:231-232
     }
     ar.off = mark;
     if (!dry) {
@@ -591,25 +706,25 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         const int h3 = (nh + 2 - 3) / 2 + 1, w3 = (nw + 2 - 3) / 2 + 1;
         // act_postprocess (dpt_block.py:353-405)
         float* a0 = ar.alloc((size_t)BN * ld[0]);
-        P.linear(t0, E, Hd.a0w, a0, ld[0], BN, ld[0], E, P.epi(A3R_EPI_NONE, Hd.a0b));
+        P.linear_f32(t0, E, Hd.a0w, a0, ld[0], BN, ld[0], E, P.epi(A3R_EPI_NONE, Hd.a0b));
         float* l0 = ar.alloc((size_t)BN * 16 * ld[0]);
         {
             a3r_epilogue e = P.epi(A3R_EPI_PIXSHUF, Hd.a0tb);
             e.ps_s = 4; e.ps_h = nh; e.ps_w = nw; e.ps_cout = ld[0];
-            P.linear(a0, ld[0], Hd.a0tw, l0, ld[0], BN, 16 * ld[0], ld[0], e);
+            P.linear_f32(a0, ld[0], Hd.a0tw, l0, ld[0], BN, 16 * ld[0], ld[0], e);
         }
         float* a1 = ar.alloc((size_t)BN * ld[1]);
-        P.linear(t1, D, Hd.a1w, a1, ld[1], BN, ld[1], D, P.epi(A3R_EPI_NONE, Hd.a1b));
+        P.linear_f32(t1, D, Hd.a1w, a1, ld[1], BN, ld[1], D, P.epi(A3R_EPI_NONE, Hd.a1b));
         float* l1 = ar.alloc((size_t)BN * 4 * ld[1]);
         {
             a3r_epilogue e = P.epi(A3R_EPI_PIXSHUF, Hd.a1tb);
             e.ps_s = 2; e.ps_h = nh; e.ps_w = nw; e.ps_cout = ld[1];
-            P.linear(a1, ld[1], Hd.a1tw, l1, ld[1], BN, 4 * ld[1], ld[1], e);
+            P.linear_f32(a1, ld[1], Hd.a1tw, l1, ld[1], BN, 4 * ld[1], ld[1], e);
         }
         float* l2 = ar.alloc((size_t)BN * ld[2]);
-        P.linear(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
+        P.linear_f32(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
         float* a3 = ar.alloc((size_t)BN * ld[3]);
-        P.linear(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
+        P.linear_f32(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
         float* l3 = ar.alloc((size_t)B * h3 * w3 * ld[3]);
         P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
         // scratch.layer_rn (no bias)

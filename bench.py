@@ -11,7 +11,7 @@ Contract (one JSON line on rank 0):
             the exchange that assembles the aligner input.
   extra   = align_iters_per_s: a3r_align_step on the config-2 graph (N=16, E=84, P=196608), timed in its own
             region after the forward region (rank-local replica; see DESIGN.md for why it is not sharded).
-  roofline      : the dominant kernel (fp32-MFMA GEMM) -- algorithmic FLOP / HIP-event duration, live.
+  roofline      : the dominant kernel (the nn.Linear GEMM) -- algorithmic FLOP / HIP-event duration, live.
   roofline_align: the fused aligner kernel -- algorithmic bytes / HIP-event duration, live.
   cpu_baseline  : the numpy/C oracle timed on this box's host cores (rank 0, N=1 only), bounded sample.
 """
@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak; the bf3 GEMM issues 6 bf16 MFMA flops per fp32 flop
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 FLOP_PER_PAIR = {(384, 512): 1969.1e9, (288, 512): 1436.1e9, (224, 224): 461.2e9}
 
@@ -140,8 +141,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pairs_per_s = world * B * a.steps / dt
-    lin = prof[0]
+    byname = {p["name"]: p for p in prof}
+    lin_bf3 = byname.get("gemm_bf3_kernel (linear, split-bf16 MFMA)")
+    use_bf3 = bool(lin_bf3 and lin_bf3["launches"])
+    lin = lin_bf3 if use_bf3 else prof[0]
     achieved = lin["work"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
+    # roofline of the dominant kernel.  fp32 MFMA kernel: algorithmic fp32 FLOP against the fp32 MFMA peak.  bf3 kernel: it
+    # executes SIX bf16 MFMA flops per algorithmic fp32 flop, so its ceiling for ALGORITHMIC flops is bf16 peak / 6.
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if use_bf3 else PEAK_F32_MFMA_TFLOPS
     kernels = {p["name"]: dict(launches=p["launches"], total_ms=round(p["ms"], 3),
                                avg_us=round(1e3 * p["ms"] / p["launches"], 2) if p["launches"] else None,
                                rate=round(p["work"] / (p["ms"] * 1e-3) / 1e12, 3) if p["ms"] > 0 else None)
@@ -156,9 +163,15 @@ def main():
                                f"{B} pairs/step/GPU, cloud_opt PointCloudOptimizer", "pairs_per_step_per_gpu": B,
                    "frames": a.frames, "edges": E, "parallelism": f"pair-shard x{world}" + (" + all-gather/step" if world > 1 else "")},
         "model_tflops_as_reference": round(pairs_per_s * flop_pair / 1e12 / world, 2) if flop_pair else None,
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)", "achieved": round(achieved, 2),
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": pmc_traffic("gemm_kernel<0>") if (B, H, W) == (12, 384, 512) else None,
+        "roofline": {"bound": "mfma",
+                     "kernel": ("gemm_bf3_kernel (nn.Linear on the bf16 matrix cores: exact 3-plane split of both fp32 operands, "
+                                "6 bf16 MFMA passes, fp32 accumulate)" if use_bf3 else "gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)"),
+                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "peak_note": ("bf16 dense MFMA peak 2500 / 6 passes = ceiling for algorithmic fp32 FLOP; executed bf16 MFMA rate = "
+                                   f"{6 * achieved:.0f} TFLOP/s; the exact-fp32 MFMA peak is {PEAK_F32_MFMA_TFLOPS}" if use_bf3
+                                   else "v_mfma_f32_32x32x2_f32 dense peak"),
+                     "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": pmc_traffic("gemm_bf3_kernel" if use_bf3 else "gemm_kernel<0>") if (B, H, W) == (12, 384, 512) else None,
                      "algorithmic_flop_per_launch": round(lin["work"] / max(lin["launches"], 1)),
                      "launches": lin["launches"], "avg_launch_us": round(1e3 * lin["ms"] / max(lin["launches"], 1), 2)},
         "kernels": kernels,
