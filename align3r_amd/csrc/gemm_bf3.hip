@@ -3,7 +3,7 @@
 //
 // Both operands arrive pre-split into three bf16 planes (bf3.h: x = x0 + x1 + x2 EXACTLY), and
 //     a b  =  a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0)  +  [a1b2 + a2b1 + a2b2, dropped: <= 2^-23 |a b|]
-// is evaluated as six v_mfma_f32_32x32x16_bf16 passes per 16-deep k-step.  Every bf16 x bf16 product is exact in the
+// is evaluated as six bf16 MFMA passes per k-step (v_mfma_f32_16x16x32_bf16, or 32x32x16).  Every bf16 x bf16 product is exact in the
 // fp32 accumulator, so the only errors are the dropped terms (below one fp32 ulp of the product) and the fp32
 // summation itself -- the same error class as the reference's fp32 GEMM (measured in tests/test_gpu_ops.py against
 // float64: not larger than the exact-fp32 MFMA kernel's).  Serves the same call sites as a3r_linear
@@ -24,18 +24,34 @@
 namespace a3r {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// s_waitcnt takes an immediate: dispatch over the counts that occur (stages in flight x DMAs per stage per wave)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 12: wait_vmcnt<12>(); break;
+        default: wait_vmcnt<0>(); break;                                    // always safe
+    }
+}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, bool FULL>
+// MF: MFMA shape -- 32: v_mfma_f32_32x32x16_bf16 (two 16-deep k-steps per BK = 32 stage); 16: v_mfma_f32_16x16x32_bf16
+// (one 32-deep k-step per stage; at the clocks the chip holds under bf16 MFMA load it delivers ~1.15x the FLOP/s of the
+// 32x32 shape, MI355X_MICROARCH.md "DVFS give-back" (7), and measured here: tools/gemm_bf3_lab.hip).
+template <int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
+    constexpr bool M16 = MF == 16;
+    static_assert(MF == 32 || (MF == 16 && BK == 32), "16x16x32 MFMA needs BK = 32");
     constexpr int NT = WM * WN * 64, KG = BK / 8, U = 3 * KG, G = KG, PER = 16 / G;
-    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int SA = BM * U, SB = BN * U, LA = SA / NT, LB = SB / NT;      // 16-byte units per stage / per thread
-    constexpr int STAGE = (SA + SB) * 16, LPS = LA + LB;
-    static_assert(SA % NT == 0 && SB % NT == 0, "stage units must divide by the thread count");
-    static_assert(NS == 2 || NS == 3, "2 or 3 stages");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int SA = BM * U, SB = BN * U;                                 // 16-byte units per stage
+    constexpr int LA = (SA + NT - 1) / NT, LB = (SB + NT - 1) / NT;         // DMAs per thread per stage (the last one may cover only the first waves)
+    static_assert(SA % 64 == 0 && SB % 64 == 0, "whole waves");
+    static_assert(WTN % 32 == 0 && WTM % 32 == 0, "wave tiles are multiples of 32 (RoPE epilogue pairs columns d, d+16)");
+    constexpr int STAGE = (SA + SB) * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // XCD-aware bijective remap (blocks b and b+8 share an XCD), then group / tile decomposition
@@ -53,92 +69,143 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const size_t pitch = (size_t)g.K * 6;
+    // Source-side rotation of a row's units (the LDS image itself is lane-linear).  32x32x16 operands: 16-lane read groups
+    // hold 16 different rows at one unit -> rotate single units by (r / PER) % G.  16x16x32 operands: a read group holds
+    // rows {0-3, 12-15} at k-group kg and rows {4-11} at kg + 1 -> rotate whole k-groups (3 units) by 2 for rows 8..15 mod 16.
+    auto src_unit = [&](int r, int cp) { return M16 ? (cp + 6 * ((r >> 3) & 1)) % U : (cp + (r / PER) % G) % U; };
     const char* srcA[LA];
     const char* srcB[LB];
 #pragma unroll
     for (int i = 0; i < LA; i++) {
-        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
+        const int slot = tid + NT * i, r = (slot / U) % BM, cp = slot % U;
         const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
-        srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + c * 16;
+        srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + src_unit(r, cp) * 16;
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
-        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
+        const int slot = tid + NT * i, r = (slot / U) % BN, cp = slot % U;
         const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
-        srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + c * 16;
+        srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + src_unit(r, cp) * 16;
     }
+    const bool lastA = (LA - 1) * NT + wave * 64 < SA, lastB = (LB - 1) * NT + wave * 64 < SB;   // wave-uniform
+    const int lps = LA + LB - ((SA % NT != 0 && !lastA) ? 1 : 0) - ((SB % NT != 0 && !lastB) ? 1 : 0);
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
         const size_t koff = (size_t)kt * (KG * 48);
 #pragma unroll
-        for (int i = 0; i < LA; i++) __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
+        for (int i = 0; i < LA; i++)
+            if (i + 1 < LA || SA % NT == 0 || lastA)
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < LB; i++)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+            if (i + 1 < LB || SB % NT == 0 || lastB)
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
     };
+    // Stage kt is consumed after (a) this wave's DMAs for it have landed -- a counted vmcnt that leaves the younger stages in
+    // flight -- and (b) the barrier, which extends (a) to the workgroup and also says every wave is done with stage kt-1,
+    // whose buffer the next issue overwrites.
+    const int nk = g.K / BK;
+    auto acquire = [&](int kt) {
+        const int rem = nk - 1 - kt, fly = rem < NS - 2 ? rem : NS - 2;
+        wait_vmcnt_dyn(fly * lps);
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+    };
+    for (int t = 0; t < NS - 1 && t < nk; t++) issue(t, t);
 
-    f32x16 acc[TM][TN];
+    if constexpr (!M16) {
+        constexpr int TM = WTM / 32, TN = WTN / 32;
+        f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-    // operand addresses: lane (row = lane & 31, k-half = lane >> 5) reads, per k-step s and plane p, unit (2 s + h) 3 + p
-    const int frow = lane & 31, fh = lane >> 5, rot = (frow / PER) % G;
-    int offA[BK / 16][3], offB[BK / 16][3];
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+        // lane (row = lane & 31, k-half = lane >> 5) reads, per k-step s and plane p, unit (2 s + h) 3 + p of its row
+        const int frow = lane & 31, fh = lane >> 5, rot = (frow / PER) % G;
+        int offA[BK / 16][3], offB[BK / 16][3];
 #pragma unroll
-    for (int s = 0; s < BK / 16; s++)
+        for (int s = 0; s < BK / 16; s++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const int c = ((2 * s + fh) * 3 + p - rot + U) % U;
+                offA[s][p] = ((wm * WTM + frow) * U + c) * 16;
+                offB[s][p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
+            }
+        for (int kt = 0; kt < nk; kt++) {
+            acquire(kt);
+            const char* sb = smem + (kt % NS) * STAGE;
+#pragma unroll
+            for (int s = 0; s < BK / 16; s++) {
+                bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[s][p] + i * 32 * U * 16);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[s][p] + j * 32 * U * 16);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        gemm_epilogue<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
+    } else {
+        constexpr int TM = WTM / 16, TN = WTN / 16;
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
+        // lane (row = lane & 15, k-group = lane >> 4) reads, per plane p, unit 3 ((kg - rot) mod 4) + p of its row
+        const int frow = lane & 15, kg = lane >> 4, rotk = 2 * ((frow >> 3) & 1);
+        int offA[3], offB[3];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
-            const int c = ((2 * s + fh) * 3 + p - rot + U) % U;
-            offA[s][p] = ((wm * WTM + frow) * U + c) * 16;
-            offB[s][p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
+            const int c = 3 * ((kg - rotk + 4) % 4) + p;
+            offA[p] = ((wm * WTM + frow) * U + c) * 16;
+            offB[p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
         }
-
-    const int nk = g.K / BK;
-    issue(0, 0);
-    if (NS == 3 && nk > 1) issue(1, 1);
-    for (int kt = 0; kt < nk; kt++) {
-        // stage kt has landed (this wave's DMAs; the barrier extends that to the workgroup) and every wave is done with
-        // stage kt-1, whose buffer the next issue overwrites
-        if (NS == 3) {
-            if (kt + 1 < nk) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-        } else {
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        }
-        const char* sb = smem + (NS == 3 ? kt % 3 : kt & 1) * STAGE;
-#pragma unroll
-        for (int s = 0; s < BK / 16; s++) {
+        for (int kt = 0; kt < nk; kt++) {
+            acquire(kt);
+            const char* sb = smem + (kt % NS) * STAGE;
             bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[s][p] + i * 32 * U * 16);
+                for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[p] + i * 16 * U * 16);
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[s][p] + j * 32 * U * 16);
+                for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[p] + j * 16 * U * 16);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        gemm_epilogue16<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
     }
-    gemm_epilogue<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
 }
 
 // fp32 [M, ldx] -> bf3 [M][K/8][3][8]: one thread per group of 8 consecutive k (32 B in, 48 contiguous bytes out)
@@ -153,9 +220,10 @@ __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict_
 }
 
 struct Bf3Tile { int bm, bn, occ; double eff; };
-// main-loop efficiencies measured on MI355X (tools/gemm_bf3_lab.hip, 18432-row ViT-L shapes): 256x128x32 8 waves
-// ~190, 128x128x16 (two workgroups per CU) ~175, 64x64x32 ~140 TFLOP/s fp32-equivalent
-static const Bf3Tile kTiles[3] = {{256, 128, 1, 1.0}, {128, 128, 2, 0.92}, {64, 64, 2, 0.72}};
+// Tile shapes and their main-loop efficiencies measured on MI355X (tools/gemm_bf3_lab.hip, 18432-row ViT-L shapes, all on
+// the 16x16x32 MFMA): 256x128 with 16 waves (4x4, one workgroup per CU) ~205, 128x64 with 4 waves (two workgroups per CU)
+// ~180-210, 64x64 ~150 TFLOP/s fp32-equivalent.  A launch of n workgroups takes ceil(n / (256 occ)) rounds.
+static const Bf3Tile kTiles[3] = {{256, 128, 1, 1.0}, {128, 64, 2, 0.95}, {64, 64, 2, 0.75}};
 
 static int choose_bf3_tile(int M, int N, int groups) {
     if (const char* f = getenv("A3R_BF3_TILE")) {      // developer override: 0 | 1 | 2
@@ -173,10 +241,11 @@ static int choose_bf3_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, bool FULL>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
 static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
-    auto kern = gemm_bf3_kernel<BM, BN, BK, WM, WN, NS, FULL>;
+    auto kern = gemm_bf3_kernel<BM, BN, BK, WM, WN, NS, MF, FULL>;
     constexpr int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -195,9 +264,9 @@ static int launch_bf3(GemmArgs& g, hipStream_t st) {
     g.tiles_per_group = g.tiles_m * g.tiles_n;
     const bool full = g.M % bm == 0 && g.N % bn == 0;
     ProfScope prof(PK_LINEAR_BF3, 2.0 * g.M * g.N * g.K * g.groups, st);
-    if (t == 0) return full ? launch_bf3_variant<256, 128, 32, 4, 2, 2, true>(g, st) : launch_bf3_variant<256, 128, 32, 4, 2, 2, false>(g, st);
-    if (t == 1) return full ? launch_bf3_variant<128, 128, 16, 2, 2, 3, true>(g, st) : launch_bf3_variant<128, 128, 16, 2, 2, 3, false>(g, st);
-    return full ? launch_bf3_variant<64, 64, 32, 2, 2, 3, true>(g, st) : launch_bf3_variant<64, 64, 32, 2, 2, 3, false>(g, st);
+    if (t == 0) return full ? launch_bf3_variant<256, 128, 32, 4, 4, 2, 16, true>(g, st) : launch_bf3_variant<256, 128, 32, 4, 4, 2, 16, false>(g, st);
+    if (t == 1) return full ? launch_bf3_variant<128, 64, 32, 2, 2, 2, 16, true>(g, st) : launch_bf3_variant<128, 64, 32, 2, 2, 2, 16, false>(g, st);
+    return full ? launch_bf3_variant<64, 64, 32, 2, 2, 3, 16, true>(g, st) : launch_bf3_variant<64, 64, 32, 2, 2, 3, 16, false>(g, st);
 }
 
 }  // namespace a3r

@@ -80,6 +80,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const GroupPtrs
     }
 }
 
+// The same epilogue over 16x16 accumulators (v_mfma_f32_16x16x32_bf16): acc[i][j] covers rows m0 + wrow0 + 16 i .. and
+// columns n0 + wcol0 + 16 j ..; element e of a lane sits at row 4 (lane>>4) + e, column lane&15.  wcol0 % 32 == 0 and TN is
+// even, so the RoPE partner column (d +- 16 inside a 32-wide half of the head) is the same lane's element of tile j ^ 1.
+template <int TM, int TN, bool FULL>
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
+                                                int wrow0, int wcol0, int lane) {
+    static_assert(TN % 2 == 0, "pairs of 16-wide tiles");
+    const a3r_epilogue& ep = g.epi;
+    const int quad = lane >> 4, lcol = lane & 15;
+    const int epi = ep.epi;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int colbase = n0 + wcol0 + j * 16;
+        const int col = colbase + lcol;
+        const bool col_ok = FULL || col < g.N;
+        const float bias = (P.bias && col_ok) ? P.bias[epi == A3R_EPI_PIXSHUF ? col % ep.ps_cout : col] : 0.f;
+        const float bias_o = (epi == A3R_EPI_ROPE && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] : 0.f;   // partner column's bias
+        const bool do_rope = epi == A3R_EPI_ROPE && colbase < ep.rope_cols;   // wave-uniform (rope_cols % 64 == 0)
+        const bool rope_x = (colbase & 32) != 0;                               // second half of the head rotates with x
+        const bool second = (colbase & 16) != 0;                               // d in [16, 32) of the half: partner is d - 16
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = m0 + wrow0 + i * 16 + quad * 4 + e;
+                float v = acc[i][j][e] + bias;
+                if (do_rope) {
+                    // pairs (d, d+16) inside each 32-wide half of the head (RoPE2D pos_embed.py:130-157)
+                    const float other = acc[i][j ^ 1][e] + bias_o;
+                    const int tok = row % ep.tokens_per_image;
+                    const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
+                    const int p = rope_x ? px : py;
+                    const float c = ep.rope_cos[p * 16 + lcol], s = ep.rope_sin[p * 16 + lcol];
+                    v = second ? v * c + other * s : v * c - other * s;
+                }
+                if ((FULL || row < g.M) && col_ok) {
+                    if (epi == A3R_EPI_GELU) v = gelu_erf(v);
+                    else if (epi == A3R_EPI_RELU) v = fmaxf(v, 0.f);
+                    else if (epi == A3R_EPI_RESID) v = P.resid[(size_t)row * g.ldc + col] + v;
+                    else if (epi == A3R_EPI_RESID2) v = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v;
+                    if (epi == A3R_EPI_PIXSHUF) {
+                        const int s = ep.ps_s, hw = ep.ps_h * ep.ps_w;
+                        const int b = row / hw, rem = row - b * hw;
+                        const int y = rem / ep.ps_w, x = rem - y * ep.ps_w;
+                        const int tap = col / ep.ps_cout, co = col - tap * ep.ps_cout;
+                        const int dy = tap / s, dx = tap - dy * s;
+                        const size_t opix = ((size_t)b * ep.ps_h * s + (y * s + dy)) * (ep.ps_w * s) + (x * s + dx);
+                        P.C[opix * ep.ps_cout + co] = v;
+                    } else {
+                        P.C[(size_t)row * g.ldc + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who) {
     if (!e) return A3R_OK;
     A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_PIXSHUF, "%s: unknown epilogue %d", who, e->epi);

@@ -17,15 +17,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// LDS image of one operand stage: rows of U = 3*BK/8 16-byte units, unpadded, unit c of row r stored at unit
-// (c - rot(r)) mod U with rot(r) = (r / (16/G)) % G, G = BK/8: conflict-free ds_read_b128 for the 32x32x16 operand.
-template <int BM, int BN, int BK, int WM, int WN, int NS>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS image of one operand stage: rows of U = 3*BK/8 16-byte units, unpadded, with the units of each row rotated on the
+// source side so that the MFMA operand reads (ds_read_b128) are conflict-free.
+// VAR bits: 1 = s_setprio(1) around the MFMA cluster; 2 = v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (BK must be 32)
+template <int BM, int BN, int BK, int WM, int WN, int NS, int VAR>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Wp, float* __restrict__ C,
                                                           int M, int N, int K) {
+    constexpr bool M16 = (VAR & 2) != 0;
     constexpr int NT = WM * WN * 64, KG = BK / 8, U = 3 * KG, G = KG, PER = 16 / G;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int SA = BM * U, SB = BN * U, LA = SA / NT, LB = SB / NT;
-    static_assert(SA % NT == 0 && SB % NT == 0, "stage slots must divide by threads");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int SA = BM * U, SB = BN * U;
+    constexpr int LA = (SA + NT - 1) / NT, LB = (SB + NT - 1) / NT;       // the last chunk may cover only the first waves
+    static_assert(SA % 64 == 0 && SB % 64 == 0, "whole waves");
     constexpr int STAGE = (SA + SB) * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = N / BN, tiles_m = M / BM, nwg = tiles_m * tiles_n;
@@ -37,100 +42,177 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const size_t pitch = (size_t)K * 6;                // bytes per bf3 row
+    // source-side rotation: 32x32x16 operands rotate single units by (r / PER) % G; 16x16x32 operands (BK = 32) rotate whole
+    // k-groups (3 units) by 2 * ((r >> 3) & 1)
+    auto src_unit = [&](int r, int cp) { return M16 ? (cp + 6 * ((r >> 3) & 1)) % U : (cp + (r / PER) % G) % U; };
     const char* srcA[LA];
     const char* srcB[LB];
 #pragma unroll
     for (int i = 0; i < LA; i++) {
-        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
-        srcA[i] = reinterpret_cast<const char*>(Ap) + (size_t)(m0 + r) * pitch + c * 16;
+        const int slot = tid + NT * i, r = (slot / U) % BM, cp = slot % U;
+        srcA[i] = reinterpret_cast<const char*>(Ap) + (size_t)(m0 + r) * pitch + src_unit(r, cp) * 16;
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
-        const int slot = tid + NT * i, r = slot / U, cp = slot % U, c = (cp + (r / PER) % G) % U;
-        srcB[i] = reinterpret_cast<const char*>(Wp) + (size_t)(n0 + r) * pitch + c * 16;
+        const int slot = tid + NT * i, r = (slot / U) % BN, cp = slot % U;
+        srcB[i] = reinterpret_cast<const char*>(Wp) + (size_t)(n0 + r) * pitch + src_unit(r, cp) * 16;
     }
+    const bool lastA = (LA - 1) * NT + wave * 64 < SA, lastB = (LB - 1) * NT + wave * 64 < SB;   // wave-uniform
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;
         const size_t koff = (size_t)kt * (KG * 48);
 #pragma unroll
         for (int i = 0; i < LA; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + NT * 16 * i), 16, 0, 0);
+            if (i + 1 < LA || SA % NT == 0 || lastA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                                                 (__attribute__((address_space(3))) void*)(base + NT * 16 * i), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < LB; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+            if (i + 1 < LB || SB % NT == 0 || lastB)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + koff),
+                                                 (__attribute__((address_space(3))) void*)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
     };
-    f32x16 acc[TM][TN];
+    // per-wave loads per stage (wave-uniform)
+    const int lps = LA + LB - ((SA % NT != 0 && !lastA) ? 1 : 0) - ((SB % NT != 0 && !lastB) ? 1 : 0);
+    auto wait_stages = [&](int stages_in_flight) {     // wait until at most `stages_in_flight` stages of this wave's DMAs are outstanding
+        const int n = stages_in_flight * lps;
+        // vmcnt takes an immediate: dispatch over the few possible values
+        switch (n) {
+            case 0: wait_vm<0>(); break;
+            case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break; case 3: wait_vm<3>(); break; case 4: wait_vm<4>(); break;
+            case 5: wait_vm<5>(); break; case 6: wait_vm<6>(); break; case 7: wait_vm<7>(); break; case 8: wait_vm<8>(); break;
+            case 9: wait_vm<9>(); break; case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break; case 12: wait_vm<12>(); break;
+            case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break; case 15: wait_vm<15>(); break; case 16: wait_vm<16>(); break;
+            case 17: wait_vm<17>(); break; case 18: wait_vm<18>(); break; case 20: wait_vm<20>(); break; case 24: wait_vm<24>(); break;
+            default: wait_vm<0>(); break;
+        }
+    };
+    const int nk = K / BK;
+    for (int t = 0; t < NS - 1 && t < nk; t++) issue(t, t);
+
+    if constexpr (!M16) {
+        constexpr int TM = WTM / 32, TN = WTN / 32;
+        f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    const int frow = lane & 31, fh = lane >> 5, rot = (frow / PER) % G;
-    int offA[BK / 16][3], offB[BK / 16][3];
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+        const int frow = lane & 31, fh = lane >> 5, rot = (frow / PER) % G;
+        int offA[BK / 16][3], offB[BK / 16][3];
 #pragma unroll
-    for (int s = 0; s < BK / 16; s++)
+        for (int s = 0; s < BK / 16; s++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const int c = ((2 * s + fh) * 3 + p - rot + U) % U;
+                offA[s][p] = ((wm * WTM + frow) * U + c) * 16;
+                offB[s][p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
+            }
+        for (int kt = 0; kt < nk; kt++) {
+            const int rem = nk - 1 - kt;
+            wait_stages(rem < NS - 2 ? rem : NS - 2);
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+            const char* sb = smem + (kt % NS) * STAGE;
+#pragma unroll
+            for (int s = 0; s < BK / 16; s++) {
+                bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[s][p] + i * 32 * U * 16);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[s][p] + j * 32 * U * 16);
+                if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    }
+                if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        const int half = lane >> 5, lcol = lane & 31;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WTN + j * 32 + lcol;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    C[(size_t)row * N + col] = acc[i][j][e];
+                }
+        }
+    } else {
+        static_assert(!M16 || BK == 32, "16x16x32 needs BK = 32");
+        constexpr int TM = WTM / 16, TN = WTN / 16;
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
+        // lane (row = lane & 15, k-group = lane >> 4) reads, per plane p, unit 3 * ((kg - rot) mod 4) + p
+        const int frow = lane & 15, kg = lane >> 4, rotk = 2 * ((frow >> 3) & 1);
+        int offA[3], offB[3];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
-            const int c = ((2 * s + fh) * 3 + p - rot + U) % U;
-            offA[s][p] = ((wm * (BM / WM) + frow) * U + c) * 16;
-            offB[s][p] = SA * 16 + ((wn * (BN / WN) + frow) * U + c) * 16;
+            const int c = 3 * ((kg - rotk + 4) % 4) + p;
+            offA[p] = ((wm * WTM + frow) * U + c) * 16;
+            offB[p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
         }
-    const int nk = K / BK;
-    constexpr int LPS = LA + LB;                        // glds per thread per stage
-    issue(0, 0);
-    if (NS == 3 && nk > 1) issue(1, 1);
-    for (int kt = 0; kt < nk; kt++) {
-        if (NS == 3) {
-            if (kt + 1 < nk) wait_vm<LPS>(); else wait_vm<0>();
+        for (int kt = 0; kt < nk; kt++) {
+            const int rem = nk - 1 - kt;
+            wait_stages(rem < NS - 2 ? rem : NS - 2);
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-        } else {
-            wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        }
-        const char* sb = smem + (NS == 3 ? kt % 3 : kt & 1) * STAGE;
-#pragma unroll
-        for (int s = 0; s < BK / 16; s++) {
+            if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+            const char* sb = smem + (kt % NS) * STAGE;
             bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[s][p] + i * 32 * U * 16);
+                for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sb + offA[p] + i * 16 * U * 16);
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[s][p] + j * 32 * U * 16);
+                for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sb + offB[p] + j * 16 * U * 16);
+            if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+            if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+        }
+        // C/D of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WTN + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int row = m0 + wm * WTM + i * 16 + (lane >> 4) * 4 + e;
+                    C[(size_t)row * N + col] = acc[i][j][e];
                 }
         }
-        if (NS == 2) {                                  // all waves done reading this buffer's partner before it is refilled
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    }
-    const int half = lane >> 5, lcol = lane & 31;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int col = n0 + wn * (BN / WN) + j * 32 + lcol;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                C[(size_t)row * N + col] = acc[i][j][e];
-            }
     }
 }
 
@@ -153,9 +235,9 @@ static void split_rows(const std::vector<float>& X, std::vector<uint16_t>& P, in
         }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int VAR = 0>
 double run(const char* name, const uint16_t* Ap, const uint16_t* Wp, float* C, int M, int N, int K, int iters) {
-    auto kern = gemm_bf3<BM, BN, BK, WM, WN, NS>;
+    auto kern = gemm_bf3<BM, BN, BK, WM, WN, NS, VAR>;
     const int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
     if (M % BM || N % BN || K % BK) { printf("%-34s skipped (shape)\n", name); return 0; }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -208,14 +290,19 @@ int main(int argc, char** argv) {
             printf("   %s: max |err| / sum|a||b| = %.3e\n", what, maxrel);
             CK(hipMemset(C, 0, (size_t)M * N * 4));
         };
-        if (mask & 1u) run<128, 128, 32, 2, 2, 2>("128x128x32 4w 2-stage", Ap, Wp, C, M, N, K, it); if (mask & 1u) check("2-stage");
-        if (mask & 2u) run<128, 128, 32, 2, 2, 3>("128x128x32 4w 3-stage", Ap, Wp, C, M, N, K, it); if (mask & 2u) check("3-stage");
-        if (mask & 4u) run<128, 128, 16, 2, 2, 3>("128x128x16 4w 3-stage", Ap, Wp, C, M, N, K, it); if (mask & 4u) check("bk16 3-stage");
-        if (mask & 8u) run<256, 128, 32, 2, 2, 2>("256x128x32 4w(128x64) 2-stage", Ap, Wp, C, M, N, K, it); if (mask & 8u) check("256x128 4w 2-stage");
-        if (mask & 16u) run<256, 128, 32, 4, 2, 2>("256x128x32 8w 2-stage", Ap, Wp, C, M, N, K, it); if (mask & 16u) check("256x128 2-stage");
-        if (mask & 32u) run<256, 256, 16, 4, 2, 3>("256x256x16 8w 3-stage", Ap, Wp, C, M, N, K, it); if (mask & 32u) check("256x256 3-stage");
-        if (mask & 64u) run<128, 64, 32, 2, 2, 3>("128x64x32 4w 3-stage", Ap, Wp, C, M, N, K, it);
-        if (mask & 128u) run<64, 64, 32, 2, 2, 3>("64x64x32 4w 3-stage", Ap, Wp, C, M, N, K, it);
+        int bit = 0;
+#define RUN(name, ...) do { if (mask & (1u << bit)) { run<__VA_ARGS__>(name, Ap, Wp, C, M, N, K, it); check(name); } bit++; } while (0)
+        RUN("256x128x32 8w NS2 m16", 256, 128, 32, 4, 2, 2, 2);
+        RUN("256x128x32 8w NS2 m16 prio", 256, 128, 32, 4, 2, 2, 3);
+        RUN("256x128x32 8w(2x4) NS2 m16", 256, 128, 32, 2, 4, 2, 2);
+        RUN("128x256x32 8w(2x4) NS2 m16", 128, 256, 32, 2, 4, 2, 2);
+        RUN("128x128x32 8w(4x2) NS2 m16", 128, 128, 32, 4, 2, 2, 2);
+        RUN("128x128x32 8w(4x2) NS3 m16", 128, 128, 32, 4, 2, 3, 2);
+        RUN("128x128x32 8w(2x4) NS3 m16", 128, 128, 32, 2, 4, 3, 2);
+        RUN("256x128x32 16w(4x4) NS2 m16", 256, 128, 32, 4, 4, 2, 2);
+        RUN("128x64x32 4w NS2 m16", 128, 64, 32, 2, 2, 2, 2);
+        RUN("128x64x32 4w NS3 m16 prio", 128, 64, 32, 2, 2, 3, 3);
+        RUN("64x64x32 4w NS3 m16", 64, 64, 32, 2, 2, 3, 2);
         CK(hipFree(Ap)); CK(hipFree(Wp)); CK(hipFree(C));
     }
     return 0;
