@@ -19,7 +19,8 @@ c_void = C.c_void_p
 class Epilogue(C.Structure):
     _fields_ = [("epi", C.c_int), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("relu_a", C.c_int),
                 ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
-                ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int)]
+                ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
+                ("out_bf3", C.c_int)]
 
 
 class GroupPtrs(C.Structure):

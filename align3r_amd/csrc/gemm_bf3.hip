@@ -295,7 +295,7 @@ extern "C" int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_gr
     A3R_CHECK_ARG(M > 0 && N > 0 && K > 0, "a3r_linear_bf3: M, N, K must be positive (got %d, %d, %d)", M, N, K);
     A3R_CHECK_ARG(K % 32 == 0, "a3r_linear_bf3: K (%d) must be a multiple of 32", K);
     A3R_CHECK_ARG(ldc >= 1, "a3r_linear_bf3: bad leading dimension ldc=%d", ldc);
-    if (int rc = check_epilogue(epi, M, N, "a3r_linear_bf3")) return rc;
+    if (int rc = check_epilogue(epi, M, N, "a3r_linear_bf3", true)) return rc;
     GemmArgs g = {};
     if (epi) g.epi = *epi;
     A3R_CHECK_ARG(!g.epi.relu_a, "a3r_linear_bf3: relu_a is only available on a3r_conv3x3");
@@ -307,6 +307,7 @@ extern "C" int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_gr
     g.groups = n_groups;
     g.lda = K; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     if (g.epi.epi != A3R_EPI_PIXSHUF) A3R_CHECK_ARG(ldc >= N, "a3r_linear_bf3: ldc (%d) < N (%d)", ldc, N);
+    if (g.epi.out_bf3) A3R_CHECK_ARG(ldc == N, "a3r_linear_bf3: out_bf3 needs ldc == N");
     return launch_bf3(g, as_stream(stream));
 }
 

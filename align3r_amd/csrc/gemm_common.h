@@ -2,6 +2,7 @@
 // launch arguments, the fused epilogue (bias / GELU / ReLU / residuals / RoPE-2D / pixel-shuffle) and argument checks.
 #pragma once
 #include "common.h"
+#include "bf3.h"
 
 namespace a3r {
 
@@ -90,6 +91,50 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
     const a3r_epilogue& ep = g.epi;
     const int quad = lane >> 4, lcol = lane & 15;
     const int epi = ep.epi;
+    if (ep.out_bf3) {
+        // bf3 output: neighbouring lanes (columns c, c+1) trade half of their four rows, so that each lane owns two rows of a
+        // column PAIR and stores one packed dword per plane and row (the even lane rows 0-1 of the quad, the odd lane rows 2-3).
+        const bool odd = lane & 1;
+        char* out = reinterpret_cast<char*>(P.C);
+        const size_t pitch = (size_t)g.N * 6;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wcol0 + j * 16 + lcol;
+            const bool col_ok = FULL || col < g.N;           // N % 8 == 0: a column pair is in or out together
+            const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[e] = acc[i][j][e] + bias;
+                    if (epi == A3R_EPI_GELU) v[e] = gelu_erf(v[e]);
+                    else if (epi == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+                const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float a0 = odd ? r0 : v[0], b0 = odd ? v[2] : r0;      // (left column, right column) of this lane's first row
+                const float a1 = odd ? r1 : v[1], b1 = odd ? v[3] : r1;
+                const int row0 = m0 + wrow0 + i * 16 + quad * 4 + (odd ? 2 : 0);
+                const int c0 = col & ~1;
+                char* d = out + (size_t)row0 * pitch + (c0 >> 3) * 48 + (c0 & 7) * 2;
+                uint32_t p0, p1, p2;
+                if (col_ok && (FULL || row0 < g.M)) {
+                    bf3_split2(a0, b0, p0, p1, p2);
+                    *reinterpret_cast<uint32_t*>(d) = p0;
+                    *reinterpret_cast<uint32_t*>(d + 16) = p1;
+                    *reinterpret_cast<uint32_t*>(d + 32) = p2;
+                }
+                if (col_ok && (FULL || row0 + 1 < g.M)) {
+                    bf3_split2(a1, b1, p0, p1, p2);
+                    *reinterpret_cast<uint32_t*>(d + pitch) = p0;
+                    *reinterpret_cast<uint32_t*>(d + pitch + 16) = p1;
+                    *reinterpret_cast<uint32_t*>(d + pitch + 32) = p2;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int colbase = n0 + wcol0 + j * 16;
@@ -137,8 +182,13 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
     }
 }
 
-static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who) {
+static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who, bool bf3_kernel = false) {
     if (!e) return A3R_OK;
+    if (e->out_bf3) {
+        A3R_CHECK_ARG(bf3_kernel, "%s: out_bf3 is only available on a3r_linear_bf3", who);
+        A3R_CHECK_ARG(N % 8 == 0 && (e->epi == A3R_EPI_NONE || e->epi == A3R_EPI_GELU || e->epi == A3R_EPI_RELU),
+                      "%s: out_bf3 needs N %% 8 == 0 and a NONE / GELU / RELU epilogue", who);
+    }
     A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_PIXSHUF, "%s: unknown epilogue %d", who, e->epi);
     if (e->epi == A3R_EPI_ROPE)
         A3R_CHECK_ARG(e->rope_cols % 64 == 0 && e->rope_cols <= N && e->tokens_per_image > 0 && e->grid_w > 0 &&

@@ -469,11 +469,16 @@ struct Plan {
         attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, M / ntok, H, ntok, ntok);
         linear(gin_from(att, att3, M, D), D, w.projw, x, D, M, D, D, epi(A3R_EPI_RESID, w.projb, resid_src));
     }
-    void mlp(const BlockW& w, const float* nw, const float* nb, float* x, int M, int D, int hidden, float* xn, float* hid,
-             float* hid3) {
+    // hid: gin [M, hidden] -- fc1's GELU epilogue writes the GEMM-input form directly (Mlp blocks.py:73-77)
+    a3r_epilogue gin_epi(int kind, const float* bias) {
+        a3r_epilogue e = epi(kind, bias);
+        e.out_bf3 = bf3() ? 1 : 0;
+        return e;
+    }
+    void mlp(const BlockW& w, const float* nw, const float* nb, float* x, int M, int D, int hidden, float* xn, float* hid) {
         ln(x, nw, nb, xn, M, D);
-        linear(xn, D, w.fc1w, hid, hidden, M, hidden, D, epi(A3R_EPI_GELU, w.fc1b));
-        linear(gin_from(hid, hid3, M, hidden), hidden, w.fc2w, x, D, M, D, hidden, epi(A3R_EPI_RESID, w.fc2b, x));
+        linear(xn, D, w.fc1w, hid, hidden, M, hidden, D, gin_epi(A3R_EPI_GELU, w.fc1b));
+        linear(hid, hidden, w.fc2w, x, D, M, D, hidden, epi(A3R_EPI_RESID, w.fc2b, x));
     }
 };
 
@@ -532,8 +537,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* qkv = ar.alloc((size_t)BN * 3 * E);
         float* att = ar.alloc((size_t)BN * E);
         float* att3 = P.gin_scratch(BN, E);
-        float* hid = ar.alloc((size_t)BN * E * c.mlp_ratio);
-        float* hid3 = P.gin_scratch(BN, E * c.mlp_ratio);
+        float* hid = P.gin_alloc(BN, E * c.mlp_ratio);
         if (!dry) {
             const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
             if ((P.rc = a3r_patchify(img1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
@@ -541,7 +545,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         P.linear(P.gin_from(cols, cols3, BN, 768), 768, m->pe_w, x, E, BN, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
         for (int i = 0; i < c.enc_depth; i++) {
             P.self_block(m->enc[i], x, x, BN, E, c.enc_num_heads, N, nw, xn, qkv, att, att3);
-            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, BN, E, E * c.mlp_ratio, xn, hid, hid3);
+            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, BN, E, E * c.mlp_ratio, xn, hid);
         }
         P.ln_f32(x, m->encn_w, m->encn_b, dry ? nullptr : feat_out, BN, E);
         if (peak) *peak = ar.peak;
@@ -577,8 +581,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* qkv = ar.alloc((size_t)M2 * 3 * E);
         float* att = ar.alloc((size_t)M2 * E);
         float* att3 = P.gin_scratch(M2, E);
-        float* hid = ar.alloc((size_t)M2 * E * c.mlp_ratio);
-        float* hid3 = P.gin_scratch(M2, E * c.mlp_ratio);
+        float* hid = P.gin_alloc(M2, E * c.mlp_ratio);
         if (!dry) {
             const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
             if ((P.rc = a3r_patchify(img1, cols, B, 3, H, W, sb, sc, sy, sx, stream))) return P.rc;
@@ -587,7 +590,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         P.linear(P.gin_from(cols, cols3, M2, 768), 768, m->pe_w, x, E, M2, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
         for (int i = 0; i < c.enc_depth; i++) {
             P.self_block(m->enc[i], x, x, M2, E, c.enc_num_heads, N, nw, xn, qkv, att, att3);
-            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, M2, E, E * c.mlp_ratio, xn, hid, hid3);
+            P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, M2, E, E * c.mlp_ratio, xn, hid);
         }
         P.ln_f32(x, m->encn_w, m->encn_b, feat, M2, E);
         // point-map patch embedding (model.py:244-248); pred_depth is [B,H,W,3]: channel stride 1
@@ -611,8 +614,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* kv = ar.alloc((size_t)M2 * 2 * D);
         float* att = ar.alloc((size_t)M2 * D);
         float* att3 = P.gin_scratch(M2, D);
-        float* hid = ar.alloc((size_t)M2 * hidden);
-        float* hid3 = P.gin_scratch(M2, hidden);
+        float* hid = P.gin_alloc(M2, hidden);
         float* pc3 = P.gin_scratch(M2, D);
         float* cur = fbuf[0];
         {
@@ -667,17 +669,15 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 // x = x + mlp(norm3(x))                                    blocks.py:190
                 P.ln(o0, w0.n3w, w0.n3b, xn, BN, D);
                 P.ln(o1, w1.n3w, w1.n3b, xn1, BN, D);
-                P.linear2(xn, xn1, D, w0.fc1w, w1.fc1w, w0.fc1b, w1.fc1b, hid, hid + (size_t)BN * hidden, hidden, BN, hidden, D,
-                          P.epi(A3R_EPI_GELU, nullptr));
-                {
-                    const float* hg = P.gin_from(hid, hid3, M2, hidden);
-                    P.linear2(hg, P.gin_at(hg, BN, hidden), hidden, w0.fc2w, w1.fc2w, w0.fc2b, w1.fc2b, o0, o1, D, BN, D, hidden,
-                              P.epi(A3R_EPI_RESID, nullptr), o0, o1);
-                }
+                float* hid1 = P.gin_at(hid, BN, hidden);
+                P.linear2(xn, xn1, D, w0.fc1w, w1.fc1w, w0.fc1b, w1.fc1b, hid, hid1, hidden, BN, hidden, D,
+                          P.gin_epi(A3R_EPI_GELU, nullptr));
+                P.linear2(hid, hid1, hidden, w0.fc2w, w1.fc2w, w0.fc2b, w1.fc2b, o0, o1, D, BN, D, hidden,
+                          P.epi(A3R_EPI_RESID, nullptr), o0, o1);
             }
             if (i < npc) {   // model.py:223-226
                 P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, xn, qkv, att, att3);
-                P.mlp(m->pc[i], m->pc[i].n2w, m->pc[i].n2b, pc, M2, D, hidden, xn, hid, hid3);
+                P.mlp(m->pc[i], m->pc[i].n2w, m->pc[i].n2b, pc, M2, D, hidden, xn, hid);
                 P.linear(P.gin_from(pc, pc3, M2, D), D, m->zc_w[i + 1], nxt, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[i + 1], nxt));
             }
             if (level == hook_a) lvl_a = nxt;

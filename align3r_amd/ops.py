@@ -65,8 +65,9 @@ def layernorm(x, w, b, eps=1e-6, out=None):
     return out
 
 
-def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None):
+def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False):
     e = Epilogue()
+    e.out_bf3 = int(out_bf3)
     e.epi = kind
     e.bias = None if bias is None else bias.data_ptr()
     e.resid = None if resid is None else resid.data_ptr()
@@ -152,9 +153,13 @@ def linear_bf3(x3: Bf3, w3: Bf3, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
     M, K, N = x3.rows, x3.K, w3.rows
     if w3.K != K:
         raise RuntimeError(f"linear_bf3: K mismatch ({K} vs {w3.K})")
+    e = make_epilogue(epi, bias, **kw)
+    if e.out_bf3:          # y in bf3 form, for the next bf3 GEMM
+        y3 = Bf3(torch.empty(M * N * 6, device=x3.data.device, dtype=torch.uint8), M, N)
+        check(_lib.load().a3r_linear_bf3(x3.data_ptr(), w3.data_ptr(), y3.data_ptr(), N, M, N, K, C.byref(e), stream_ptr()), "linear_bf3")
+        return y3
     if out is None:
         out = torch.empty((M, N), device=x3.data.device, dtype=torch.float32)
-    e = make_epilogue(epi, bias, **kw)
     check(_lib.load().a3r_linear_bf3(x3.data_ptr(), w3.data_ptr(), ptr(out), out.shape[-1] if epi != _lib.EPI_PIXSHUF else e.ps_cout,
                                      M, N, K, C.byref(e), stream_ptr()), "linear_bf3")
     return out

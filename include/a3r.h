@@ -92,6 +92,9 @@ typedef struct {
     const float* rope_sin;
     /* PIXSHUF */
     int ps_s, ps_h, ps_w, ps_cout;  /* stride s, input map h x w, output channels */
+    /* a3r_linear_bf3 only: write y in bf3 form ([M][N/8][3][8] bf16, N % 8 == 0, ldc = N) instead of fp32, for outputs that
+     * only feed the next bf3 GEMM (Mlp: fc1 + GELU -> fc2, blocks.py:73-77).  NONE / GELU / RELU epilogues. */
+    int out_bf3;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats

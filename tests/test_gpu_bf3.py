@@ -72,6 +72,23 @@ def test_linear_bf3_every_tile_shape(ops, monkeypatch, tile, M, N, K):
         assert rel_err(cpu(y), cpu(want)) < TOL
 
 
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1001, 384, 128)])
+def test_linear_bf3_output_in_bf3_form(ops, monkeypatch, tile, M, N, K):
+    """fc1 + GELU writing the next GEMM's input directly == the fp32 result split afterwards, bit for bit."""
+    from align3r_amd import _lib
+    monkeypatch.setenv("A3R_BF3_TILE", tile)
+    x3, w3, b = ops.split_bf3(rnd(M, K, seed=1)), ops.split_bf3(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
+    for epi in (_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RELU):
+        y3 = ops.linear_bf3(x3, w3, b, epi=epi, out_bf3=True)
+        want = ops.split_bf3(ops.linear_bf3(x3, w3, b, epi=epi))
+        assert torch.equal(y3.data, want.data)
+    with pytest.raises(RuntimeError, match="out_bf3"):
+        ops.linear_bf3(x3, w3, b, epi=_lib.EPI_RESID, resid=rnd(M, N, seed=4), out_bf3=True)
+    with pytest.raises(RuntimeError, match="out_bf3"):
+        ops.linear(rnd(M, K, seed=1), rnd(N, K, seed=2), b, out_bf3=True)
+
+
 def test_linear_bf3_error_not_larger_than_fp32_mfma(ops):
     """|err| / sum|x||w| against float64 for K = 4096: the bf3 GEMM is as accurate as the exact-fp32 MFMA GEMM."""
     M, N, K = 512, 512, 4096
