@@ -41,7 +41,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // MF: MFMA shape -- 32: v_mfma_f32_32x32x16_bf16 (two 16-deep k-steps per BK = 32 stage); 16: v_mfma_f32_16x16x32_bf16
 // (one 32-deep k-step per stage; at the clocks the chip holds under bf16 MFMA load it delivers ~1.15x the FLOP/s of the
 // 32x32 shape, MI355X_MICROARCH.md "DVFS give-back" (7), and measured here: tools/gemm_bf3_lab.hip).
-template <int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
+// all-zero source for the padding taps of the implicit conv (LDS-DMA has no predicated zero fill)
+__device__ __attribute__((aligned(16))) unsigned int g_bf3_zero[4];
+
+// AMODE 0: A is a bf3 matrix [M, K].  AMODE 1: implicit 3x3 conv (padding 1, stride 1 or 2) over a bf3 channels-last map
+// x [B, H, W, Cin]: row m of A is output pixel m, its K axis is (tap, ci) -- stage kt covers BK channels of ONE tap, i.e.
+// 6 BK contiguous bytes of one input pixel, or zeros where the tap falls into the padding.
+template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     constexpr bool M16 = MF == 16;
     static_assert(MF == 32 || (MF == 16 && BK == 32), "16x16x32 MFMA needs BK = 32");
@@ -73,13 +79,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     // hold 16 different rows at one unit -> rotate single units by (r / PER) % G.  16x16x32 operands: a read group holds
     // rows {0-3, 12-15} at k-group kg and rows {4-11} at kg + 1 -> rotate whole k-groups (3 units) by 2 for rows 8..15 mod 16.
     auto src_unit = [&](int r, int cp) { return M16 ? (cp + 6 * ((r >> 3) & 1)) % U : (cp + (r / PER) % G) % U; };
-    const char* srcA[LA];
+    const char* srcA[LA];       // AMODE 0: row pointer at k = 0; AMODE 1: the centre tap's pixel, channel 0
+    int tapsA[LA];              // AMODE 1: bit t set <=> tap t = 3 dy + dx lies inside the map
     const char* srcB[LB];
 #pragma unroll
     for (int i = 0; i < LA; i++) {
         const int slot = tid + NT * i, r = (slot / U) % BM, cp = slot % U;
         const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
-        srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + src_unit(r, cp) * 16;
+        if (AMODE == 0) {
+            srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + src_unit(r, cp) * 16;
+            tapsA[i] = 0;
+        } else {
+            const int hw = g.cHo * g.cWo;
+            const int b = gm / hw, rem = gm - b * hw;
+            const int oy = rem / g.cWo, ox = rem - oy * g.cWo;
+            const int iy = oy * g.cStride, ix = ox * g.cStride;     // centre tap
+            srcA[i] = reinterpret_cast<const char*>(P.A) + (((size_t)b * g.cH + iy) * g.cW + ix) * ((size_t)g.cCin * 6) + src_unit(r, cp) * 16;
+            int mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int yy = iy + t / 3 - 1, xx = ix + t % 3 - 1;
+                if (yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW) mask |= 1 << t;
+            }
+            tapsA[i] = mask;
+        }
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
@@ -89,13 +112,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     }
     const bool lastA = (LA - 1) * NT + wave * 64 < SA, lastB = (LB - 1) * NT + wave * 64 < SB;   // wave-uniform
     const int lps = LA + LB - ((SA % NT != 0 && !lastA) ? 1 : 0) - ((SB % NT != 0 && !lastB) ? 1 : 0);
+    int c_tap = 0, c_ci = 0;                                          // AMODE 1: (tap, first channel) of the next stage to issue (stages are issued in order)
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
         const size_t koff = (size_t)kt * (KG * 48);
+        long delta = 0;
+        if (AMODE == 1) {
+            const int dy = c_tap / 3, dx = c_tap - 3 * dy;
+            delta = ((long)(dy - 1) * g.cW + (dx - 1)) * ((long)g.cCin * 6) + (long)c_ci * 6;
+        }
 #pragma unroll
         for (int i = 0; i < LA; i++)
-            if (i + 1 < LA || SA % NT == 0 || lastA)
-                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
+            if (i + 1 < LA || SA % NT == 0 || lastA) {
+                const char* src = AMODE == 0 ? srcA[i] + koff
+                                             : ((tapsA[i] >> c_tap) & 1 ? srcA[i] + delta : reinterpret_cast<const char*>(g_bf3_zero));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NT * 16 * i), 16, 0, 0);
+            }
+        if (AMODE == 1) {
+            c_ci += BK;
+            if (c_ci >= g.cCin) { c_ci = 0; c_tap++; }
+        }
 #pragma unroll
         for (int i = 0; i < LB; i++)
             if (i + 1 < LB || SB % NT == 0 || lastB)
@@ -241,9 +277,9 @@ static int choose_bf3_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
+template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
 static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
-    auto kern = gemm_bf3_kernel<BM, BN, BK, WM, WN, NS, MF, FULL>;
+    auto kern = gemm_bf3_kernel<AMODE, BM, BN, BK, WM, WN, NS, MF, FULL>;
     constexpr int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
@@ -256,6 +292,7 @@ static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
     return A3R_OK;
 }
 
+template <int AMODE>
 static int launch_bf3(GemmArgs& g, hipStream_t st) {
     const int t = choose_bf3_tile(g.M, g.N, g.groups);
     const int bm = kTiles[t].bm, bn = kTiles[t].bn;
@@ -263,10 +300,10 @@ static int launch_bf3(GemmArgs& g, hipStream_t st) {
     g.tiles_n = (g.N + bn - 1) / bn;
     g.tiles_per_group = g.tiles_m * g.tiles_n;
     const bool full = g.M % bm == 0 && g.N % bn == 0;
-    ProfScope prof(PK_LINEAR_BF3, 2.0 * g.M * g.N * g.K * g.groups, st);
-    if (t == 0) return full ? launch_bf3_variant<256, 128, 32, 4, 4, 2, 16, true>(g, st) : launch_bf3_variant<256, 128, 32, 4, 4, 2, 16, false>(g, st);
-    if (t == 1) return full ? launch_bf3_variant<128, 64, 32, 2, 2, 2, 16, true>(g, st) : launch_bf3_variant<128, 64, 32, 2, 2, 2, 16, false>(g, st);
-    return full ? launch_bf3_variant<64, 64, 32, 2, 2, 3, 16, true>(g, st) : launch_bf3_variant<64, 64, 32, 2, 2, 3, 16, false>(g, st);
+    ProfScope prof(AMODE == 0 ? PK_LINEAR_BF3 : PK_CONV_BF3, 2.0 * g.M * g.N * g.K * g.groups, st);
+    if (t == 0) return full ? launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, true>(g, st) : launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, false>(g, st);
+    if (t == 1) return full ? launch_bf3_variant<AMODE, 128, 64, 32, 2, 2, 2, 16, true>(g, st) : launch_bf3_variant<AMODE, 128, 64, 32, 2, 2, 2, 16, false>(g, st);
+    return full ? launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, true>(g, st) : launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, false>(g, st);
 }
 
 }  // namespace a3r
@@ -308,11 +345,33 @@ extern "C" int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_gr
     g.lda = K; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     if (g.epi.epi != A3R_EPI_PIXSHUF) A3R_CHECK_ARG(ldc >= N, "a3r_linear_bf3: ldc (%d) < N (%d)", ldc, N);
     if (g.epi.out_bf3) A3R_CHECK_ARG(ldc == N, "a3r_linear_bf3: out_bf3 needs ldc == N");
-    return launch_bf3(g, as_stream(stream));
+    return launch_bf3<0>(g, as_stream(stream));
 }
 
 extern "C" int a3r_linear_bf3(const void* x3, const void* w3, float* y, int ldc, int M, int N, int K, const a3r_epilogue* epi,
                               void* stream) {
     a3r_group_ptrs_bf3 p = {x3, w3, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr};
     return a3r_linear_bf3_grouped(&p, 1, ldc, M, N, K, epi, stream);
+}
+
+extern "C" int a3r_conv3x3_bf3(const void* x3, const void* wp3, float* y, int B, int H, int W, int Cin, int Cout, int stride,
+                               const a3r_epilogue* epi, void* stream) {
+    A3R_CHECK_ARG(x3 && wp3 && y, "a3r_conv3x3_bf3: null pointer");
+    A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0, "a3r_conv3x3_bf3: bad shape");
+    A3R_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "a3r_conv3x3_bf3: Cin (%d) must be a multiple of 32", Cin);
+    A3R_CHECK_ARG(stride == 1 || stride == 2, "a3r_conv3x3_bf3: stride must be 1 or 2");
+    GemmArgs g = {};
+    g.cH = H; g.cW = W; g.cCin = Cin; g.cStride = stride;
+    g.cHo = (H + 2 - 3) / stride + 1;
+    g.cWo = (W + 2 - 3) / stride + 1;
+    g.lda = 0; g.ldc = Cout;
+    g.M = B * g.cHo * g.cWo; g.N = Cout; g.K = 9 * Cin;
+    if (int rc = check_epilogue(epi, g.M, g.N, "a3r_conv3x3_bf3", true)) return rc;
+    if (epi) g.epi = *epi;
+    A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF && g.epi.epi != A3R_EPI_ROPE, "a3r_conv3x3_bf3: unsupported epilogue");
+    A3R_CHECK_ARG(!g.epi.relu_a, "a3r_conv3x3_bf3: relu_a is not available (the producer writes the pre-activated bf3 input: aux_relu)");
+    g.groups = 1;
+    g.grp[0] = {static_cast<const float*>(x3), static_cast<const float*>(wp3), y, g.epi.bias, g.epi.resid, g.epi.resid2};
+    if (int rc = check_group(g.grp[0], g.epi.epi, "a3r_conv3x3_bf3")) return rc;
+    return launch_bf3<1>(g, as_stream(stream));
 }

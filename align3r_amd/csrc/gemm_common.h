@@ -84,6 +84,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const GroupPtrs
 // The same epilogue over 16x16 accumulators (v_mfma_f32_16x16x32_bf16): acc[i][j] covers rows m0 + wrow0 + 16 i .. and
 // columns n0 + wcol0 + 16 j ..; element e of a lane sits at row 4 (lane>>4) + e, column lane&15.  wcol0 % 32 == 0 and TN is
 // even, so the RoPE partner column (d +- 16 inside a 32-wide half of the head) is the same lane's element of tile j ^ 1.
+// bf3 outputs (out_bf3: instead of the fp32 store; aux_bf3: in addition to it, optionally through a ReLU): neighbouring
+// lanes (columns c, c+1) trade half of their four rows, so that each lane owns two rows of a column PAIR and stores one
+// packed dword per plane and row (the even lane rows 0-1 of its quad, the odd lane rows 2-3).
 template <int TM, int TN, bool FULL>
 __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
                                                 int wrow0, int wcol0, int lane) {
@@ -91,50 +94,10 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
     const a3r_epilogue& ep = g.epi;
     const int quad = lane >> 4, lcol = lane & 15;
     const int epi = ep.epi;
-    if (ep.out_bf3) {
-        // bf3 output: neighbouring lanes (columns c, c+1) trade half of their four rows, so that each lane owns two rows of a
-        // column PAIR and stores one packed dword per plane and row (the even lane rows 0-1 of the quad, the odd lane rows 2-3).
-        const bool odd = lane & 1;
-        char* out = reinterpret_cast<char*>(P.C);
-        const size_t pitch = (size_t)g.N * 6;
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wcol0 + j * 16 + lcol;
-            const bool col_ok = FULL || col < g.N;           // N % 8 == 0: a column pair is in or out together
-            const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    v[e] = acc[i][j][e] + bias;
-                    if (epi == A3R_EPI_GELU) v[e] = gelu_erf(v[e]);
-                    else if (epi == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
-                }
-                const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
-                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
-                const float a0 = odd ? r0 : v[0], b0 = odd ? v[2] : r0;      // (left column, right column) of this lane's first row
-                const float a1 = odd ? r1 : v[1], b1 = odd ? v[3] : r1;
-                const int row0 = m0 + wrow0 + i * 16 + quad * 4 + (odd ? 2 : 0);
-                const int c0 = col & ~1;
-                char* d = out + (size_t)row0 * pitch + (c0 >> 3) * 48 + (c0 & 7) * 2;
-                uint32_t p0, p1, p2;
-                if (col_ok && (FULL || row0 < g.M)) {
-                    bf3_split2(a0, b0, p0, p1, p2);
-                    *reinterpret_cast<uint32_t*>(d) = p0;
-                    *reinterpret_cast<uint32_t*>(d + 16) = p1;
-                    *reinterpret_cast<uint32_t*>(d + 32) = p2;
-                }
-                if (col_ok && (FULL || row0 + 1 < g.M)) {
-                    bf3_split2(a1, b1, p0, p1, p2);
-                    *reinterpret_cast<uint32_t*>(d + pitch) = p0;
-                    *reinterpret_cast<uint32_t*>(d + pitch + 16) = p1;
-                    *reinterpret_cast<uint32_t*>(d + pitch + 32) = p2;
-                }
-            }
-        }
-        return;
-    }
+    const bool odd = lane & 1;
+    char* out3 = ep.out_bf3 ? reinterpret_cast<char*>(P.C) : static_cast<char*>(ep.aux_bf3);
+    const bool relu3 = !ep.out_bf3 && ep.aux_relu;
+    const size_t pitch3 = (size_t)g.N * 6;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int colbase = n0 + wcol0 + j * 16;
@@ -147,10 +110,11 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
         const bool second = (colbase & 16) != 0;                               // d in [16, 32) of the half: partner is d - 16
 #pragma unroll
         for (int i = 0; i < TM; i++) {
+            float v[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int row = m0 + wrow0 + i * 16 + quad * 4 + e;
-                float v = acc[i][j][e] + bias;
+                v[e] = acc[i][j][e] + bias;
                 if (do_rope) {
                     // pairs (d, d+16) inside each 32-wide half of the head (RoPE2D pos_embed.py:130-157)
                     const float other = acc[i][j ^ 1][e] + bias_o;
@@ -158,13 +122,14 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
                     const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
                     const int p = rope_x ? px : py;
                     const float c = ep.rope_cos[p * 16 + lcol], s = ep.rope_sin[p * 16 + lcol];
-                    v = second ? v * c + other * s : v * c - other * s;
+                    v[e] = second ? v[e] * c + other * s : v[e] * c - other * s;
                 }
-                if ((FULL || row < g.M) && col_ok) {
-                    if (epi == A3R_EPI_GELU) v = gelu_erf(v);
-                    else if (epi == A3R_EPI_RELU) v = fmaxf(v, 0.f);
-                    else if (epi == A3R_EPI_RESID) v = P.resid[(size_t)row * g.ldc + col] + v;
-                    else if (epi == A3R_EPI_RESID2) v = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v;
+                const bool ok = (FULL || row < g.M) && col_ok;
+                if (epi == A3R_EPI_GELU) v[e] = gelu_erf(v[e]);
+                else if (epi == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                else if (epi == A3R_EPI_RESID) { if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + v[e]; }
+                else if (epi == A3R_EPI_RESID2) { if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v[e]; }
+                if (ok && !ep.out_bf3) {
                     if (epi == A3R_EPI_PIXSHUF) {
                         const int s = ep.ps_s, hw = ep.ps_h * ep.ps_w;
                         const int b = row / hw, rem = row - b * hw;
@@ -172,10 +137,36 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
                         const int tap = col / ep.ps_cout, co = col - tap * ep.ps_cout;
                         const int dy = tap / s, dx = tap - dy * s;
                         const size_t opix = ((size_t)b * ep.ps_h * s + (y * s + dy)) * (ep.ps_w * s) + (x * s + dx);
-                        P.C[opix * ep.ps_cout + co] = v;
+                        P.C[opix * ep.ps_cout + co] = v[e];
                     } else {
-                        P.C[(size_t)row * g.ldc + col] = v;
+                        P.C[(size_t)row * g.ldc + col] = v[e];
                     }
+                }
+            }
+            if (out3) {                                       // wave-uniform
+                if (relu3) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+                }
+                const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float a0 = odd ? r0 : v[0], b0 = odd ? v[2] : r0;      // (left, right column) of this lane's first row
+                const float a1 = odd ? r1 : v[1], b1 = odd ? v[3] : r1;
+                const int row0 = m0 + wrow0 + i * 16 + quad * 4 + (odd ? 2 : 0);
+                const int c0 = col & ~1;                                      // N % 8 == 0: a column pair is in or out together
+                char* d = out3 + (size_t)row0 * pitch3 + (c0 >> 3) * 48 + (c0 & 7) * 2;
+                uint32_t p0, p1, p2;
+                if (col_ok && (FULL || row0 < g.M)) {
+                    bf3_split2(a0, b0, p0, p1, p2);
+                    *reinterpret_cast<uint32_t*>(d) = p0;
+                    *reinterpret_cast<uint32_t*>(d + 16) = p1;
+                    *reinterpret_cast<uint32_t*>(d + 32) = p2;
+                }
+                if (col_ok && (FULL || row0 + 1 < g.M)) {
+                    bf3_split2(a1, b1, p0, p1, p2);
+                    *reinterpret_cast<uint32_t*>(d + pitch3) = p0;
+                    *reinterpret_cast<uint32_t*>(d + pitch3 + 16) = p1;
+                    *reinterpret_cast<uint32_t*>(d + pitch3 + 32) = p2;
                 }
             }
         }
@@ -185,9 +176,15 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
 static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who, bool bf3_kernel = false) {
     if (!e) return A3R_OK;
     if (e->out_bf3) {
-        A3R_CHECK_ARG(bf3_kernel, "%s: out_bf3 is only available on a3r_linear_bf3", who);
+        A3R_CHECK_ARG(bf3_kernel, "%s: out_bf3 is only available on the bf3 kernels", who);
         A3R_CHECK_ARG(N % 8 == 0 && (e->epi == A3R_EPI_NONE || e->epi == A3R_EPI_GELU || e->epi == A3R_EPI_RELU),
                       "%s: out_bf3 needs N %% 8 == 0 and a NONE / GELU / RELU epilogue", who);
+        A3R_CHECK_ARG(!e->aux_bf3, "%s: out_bf3 and aux_bf3 are exclusive", who);
+    }
+    if (e->aux_bf3) {
+        A3R_CHECK_ARG(bf3_kernel, "%s: aux_bf3 is only available on the bf3 kernels", who);
+        A3R_CHECK_ARG(N % 8 == 0 && e->epi != A3R_EPI_PIXSHUF && (reinterpret_cast<uintptr_t>(e->aux_bf3) & 15) == 0,
+                      "%s: aux_bf3 needs N %% 8 == 0, a 16-byte aligned buffer and no PIXSHUF", who);
     }
     A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_PIXSHUF, "%s: unknown epilogue %d", who, e->epi);
     if (e->epi == A3R_EPI_ROPE)

@@ -168,6 +168,14 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
         twin("patch_embed_point_cloud.proj.weight", D, 768);
         twin("decoder_embed.weight", D, E);
         for (int i = 0; i <= n_pc_blocks(c); i++) twin("zero_convs." + std::to_string(i) + ".0.weight", D, D);
+        // DPT heads: every packed 3x3 conv weight [Cout, 9 Cin] and the 1x1 out_conv of the fusion blocks
+        std::vector<PackItem> convs;
+        for (const PackItem& it : v)
+            if (it.kind == 0) convs.push_back(it);
+        for (const PackItem& it : convs) twin(it.name, it.a, 9 * it.b);
+        for (int h = 1; h <= 2; h++)
+            for (int r = 1; r <= 4; r++)
+                twin("downstream_head" + std::to_string(h) + ".dpt.scratch.refinenet" + std::to_string(r) + ".out_conv.weight", F, F);
     }
     *total = off;
     return v;
@@ -426,6 +434,24 @@ struct Plan {
             rc = a3r_linear_grouped(g, 2, lda, ldc, M, N, K, &e, stream);
         }
     }
+    // ---- bf3-mode helpers of the DPT heads
+    float* alloc3(size_t rows, int K) { return ar.alloc(rows * K * 3 / 2); }      // a bf3 [rows, K] buffer
+    void split(const float* x, float* y3, long M, int K) {
+        if (skip()) return;
+        traced("split_bf3", (int)M, K);
+        rc = a3r_split_bf3(x, K, y3, M, K, stream);
+    }
+    void conv3(const float* x3, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
+        if (skip()) return;
+        traced("conv3x3_bf3", H, W, Cin);
+        const void* w3 = twin(wp);
+        if (w3) rc = a3r_conv3x3_bf3(x3, w3, y, B, H, W, Cin, Cout, stride, &e, stream);
+    }
+    void up3(const float* x, float* y3, int B, int H, int W, int C, int Hc, int Wc) {
+        if (skip()) return;
+        traced("upsample2x_bf3", H, W, C);
+        rc = a3r_upsample2x_bf3(x, y3, B, H, W, C, Hc, Wc, stream);
+    }
     // LayerNorm whose output feeds a GEMM (written directly in bf3 form in bf3 mode)
     void ln(const float* x, const float* w, const float* b, float* yg, int M, int D) {
         if (skip()) return;
@@ -511,6 +537,47 @@ float* fusion(Plan& P, const FusionW& w, const float* x0, const float* x1, bool 
     P.up(o, u, B, H, W, F, Hc, Wc);
     float* r = ar.alloc((size_t)B * Hc * Wc * F);
     P.linear_f32(u, F, w.ow, r, F, B * Hc * Wc, F, F, P.epi(A3R_EPI_NONE, w.ob));
+    return r;
+}
+
+// ---- the same blocks on the bf3 kernels.  A conv input lives in bf3 form; where the fp32 value is also needed (skip
+// connections) the producer writes both (aux_bf3), pre-activated when the consumer is an RCU (which starts with a ReLU).
+// x: fp32 [B,H,W,F]; xr3: bf3 of relu(x); tmp3: bf3 scratch; out: fp32; out_r3: bf3 of relu(out) or null
+void rcu_bf3(Plan& P, const RcuW& w, const float* x, const float* xr3, const float* extra, float* tmp3, float* out, float* out_r3,
+             int B, int H, int W, int F) {
+    a3r_epilogue e1 = P.epi(A3R_EPI_RELU, w.c1b);
+    e1.out_bf3 = 1;
+    P.conv3(xr3, w.c1w, tmp3, B, H, W, F, F, 1, e1);
+    a3r_epilogue e2 = extra ? P.epi(A3R_EPI_RESID2, w.c2b, x, extra) : P.epi(A3R_EPI_RESID, w.c2b, x);
+    if (out_r3) { e2.aux_bf3 = out_r3; e2.aux_relu = 1; }
+    P.conv3(tmp3, w.c2w, out, B, H, W, F, F, 1, e2);
+}
+
+// returns fp32 [B, Hc, Wc, F], or its bf3 form when `last` (refinenet1's output only feeds head.0's 3x3 conv)
+float* fusion_bf3(Plan& P, const FusionW& w, const float* x0, const float* x0r3, const float* x1, const float* x1r3, bool two, int B,
+                  int H, int W, int F, int Hc, int Wc, bool last) {
+    Arena& ar = P.ar;
+    const size_t px = (size_t)B * H * W, n = px * F;
+    float* tmp3 = P.alloc3(px, F);
+    const float *cur, *cur3;
+    if (two) {
+        float* s = ar.alloc(n);
+        float* sr3 = P.alloc3(px, F);
+        rcu_bf3(P, w.r1, x1, x1r3, x0, tmp3, s, sr3, B, H, W, F);     // output + resConfUnit1(xs[1])
+        cur = s; cur3 = sr3;
+    } else {
+        cur = x0; cur3 = x0r3;
+    }
+    float* o = ar.alloc(n);
+    rcu_bf3(P, w.r2, cur, cur3, nullptr, tmp3, o, nullptr, B, H, W, F);
+    const size_t opx = (size_t)B * Hc * Wc;
+    float* u3 = P.alloc3(opx, F);
+    P.up3(o, u3, B, H, W, F, Hc, Wc);
+    a3r_epilogue e = P.epi(A3R_EPI_NONE, w.ob);
+    float* r;
+    if (last) { r = P.alloc3(opx, F); e.out_bf3 = 1; }
+    else r = ar.alloc(opx * F);
+    P.linear(u3, F, w.ow, r, F, (int)opx, F, F, e);
     return r;
 }
 
@@ -725,30 +792,76 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         P.linear_f32(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
         float* a3 = ar.alloc((size_t)BN * ld[3]);
         P.linear_f32(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
-        float* l3 = ar.alloc((size_t)B * h3 * w3 * ld[3]);
-        P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
-        // scratch.layer_rn (no bias)
-        float* r0 = ar.alloc((size_t)BN * 16 * F);
-        P.conv(l0, Hd.rn[0], r0, B, 4 * nh, 4 * nw, ld[0], F, 1, P.epi(A3R_EPI_NONE, nullptr));
-        float* r1 = ar.alloc((size_t)BN * 4 * F);
-        P.conv(l1, Hd.rn[1], r1, B, 2 * nh, 2 * nw, ld[1], F, 1, P.epi(A3R_EPI_NONE, nullptr));
-        float* r2 = ar.alloc((size_t)BN * F);
-        P.conv(l2, Hd.rn[2], r2, B, nh, nw, ld[2], F, 1, P.epi(A3R_EPI_NONE, nullptr));
-        float* r3 = ar.alloc((size_t)B * h3 * w3 * F);
-        P.conv(l3, Hd.rn[3], r3, B, h3, w3, ld[3], F, 1, P.epi(A3R_EPI_NONE, nullptr));
-        // refinement (dpt_head.py:57-60)
-        float* p4 = fusion(P, Hd.ref[3], r3, nullptr, false, B, h3, w3, F, nh, nw);
-        float* p3 = fusion(P, Hd.ref[2], p4, r2, true, B, nh, nw, F, 2 * nh, 2 * nw);
-        float* p2 = fusion(P, Hd.ref[1], p3, r1, true, B, 2 * nh, 2 * nw, F, 4 * nh, 4 * nw);
-        float* p1 = fusion(P, Hd.ref[0], p2, r0, true, B, 4 * nh, 4 * nw, F, 8 * nh, 8 * nw);
-        // head (dpt_block.py:323-330)
+        float* l3 = P.gin_alloc((size_t)B * h3 * w3, ld[3]);          // only feeds layer4_rn's conv: bf3 in bf3 mode
+        if (!P.bf3()) {
+            P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
+        } else {
+            float* a33 = P.alloc3(BN, ld[3]);
+            P.split(a3, a33, BN, ld[3]);
+            a3r_epilogue e = P.epi(A3R_EPI_NONE, Hd.a3cb);
+            e.out_bf3 = 1;
+            P.conv3(a33, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, e);
+        }
+        float* h2 = nullptr;
         const int Hh = 8 * nh, Wh = 8 * nw;
-        float* h0 = ar.alloc((size_t)B * Hh * Wh * (F / 2));
-        P.conv(p1, Hd.h0w, h0, B, Hh, Wh, F, F / 2, 1, P.epi(A3R_EPI_NONE, Hd.h0b));
-        float* hu = ar.alloc((size_t)B * H * W * (F / 2));
-        P.up(h0, hu, B, Hh, Wh, F / 2, H, W);
-        float* h2 = ar.alloc((size_t)B * H * W * L);
-        P.conv(hu, Hd.h2w, h2, B, H, W, F / 2, L, 1, P.epi(A3R_EPI_RELU, Hd.h2b));
+        if (!P.bf3()) {
+            // scratch.layer_rn (no bias)
+            float* r0 = ar.alloc((size_t)BN * 16 * F);
+            P.conv(l0, Hd.rn[0], r0, B, 4 * nh, 4 * nw, ld[0], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+            float* r1 = ar.alloc((size_t)BN * 4 * F);
+            P.conv(l1, Hd.rn[1], r1, B, 2 * nh, 2 * nw, ld[1], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+            float* r2 = ar.alloc((size_t)BN * F);
+            P.conv(l2, Hd.rn[2], r2, B, nh, nw, ld[2], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+            float* r3 = ar.alloc((size_t)B * h3 * w3 * F);
+            P.conv(l3, Hd.rn[3], r3, B, h3, w3, ld[3], F, 1, P.epi(A3R_EPI_NONE, nullptr));
+            // refinement (dpt_head.py:57-60)
+            float* p4 = fusion(P, Hd.ref[3], r3, nullptr, false, B, h3, w3, F, nh, nw);
+            float* p3 = fusion(P, Hd.ref[2], p4, r2, true, B, nh, nw, F, 2 * nh, 2 * nw);
+            float* p2 = fusion(P, Hd.ref[1], p3, r1, true, B, 2 * nh, 2 * nw, F, 4 * nh, 4 * nw);
+            float* p1 = fusion(P, Hd.ref[0], p2, r0, true, B, 4 * nh, 4 * nw, F, 8 * nh, 8 * nw);
+            // head (dpt_block.py:323-330)
+            float* h0 = ar.alloc((size_t)B * Hh * Wh * (F / 2));
+            P.conv(p1, Hd.h0w, h0, B, Hh, Wh, F, F / 2, 1, P.epi(A3R_EPI_NONE, Hd.h0b));
+            float* hu = ar.alloc((size_t)B * H * W * (F / 2));
+            P.up(h0, hu, B, Hh, Wh, F / 2, H, W);
+            h2 = ar.alloc((size_t)B * H * W * L);
+            P.conv(hu, Hd.h2w, h2, B, H, W, F / 2, L, 1, P.epi(A3R_EPI_RELU, Hd.h2b));
+
+        } else {
+            // conv inputs in bf3 form (small maps: plain split passes)
+            float* l03 = P.alloc3((size_t)BN * 16, ld[0]);
+            P.split(l0, l03, (long)BN * 16, ld[0]);
+            float* l13 = P.alloc3((size_t)BN * 4, ld[1]);
+            P.split(l1, l13, (long)BN * 4, ld[1]);
+            float* l23 = P.alloc3(BN, ld[2]);
+            P.split(l2, l23, BN, ld[2]);
+            // scratch.layer_rn (no bias): fp32 for the skip connection + pre-activated bf3 for the first RCU conv
+            float* r0 = ar.alloc((size_t)BN * 16 * F);
+            float* r0r3 = P.alloc3((size_t)BN * 16, F);
+            float* r1 = ar.alloc((size_t)BN * 4 * F);
+            float* r1r3 = P.alloc3((size_t)BN * 4, F);
+            float* r2 = ar.alloc((size_t)BN * F);
+            float* r2r3 = P.alloc3(BN, F);
+            float* r3 = ar.alloc((size_t)B * h3 * w3 * F);
+            float* r3r3 = P.alloc3((size_t)B * h3 * w3, F);
+            auto rn_epi = [&](float* aux) { a3r_epilogue e = P.epi(A3R_EPI_NONE, nullptr); e.aux_bf3 = aux; e.aux_relu = 1; return e; };
+            P.conv3(l03, Hd.rn[0], r0, B, 4 * nh, 4 * nw, ld[0], F, 1, rn_epi(r0r3));
+            P.conv3(l13, Hd.rn[1], r1, B, 2 * nh, 2 * nw, ld[1], F, 1, rn_epi(r1r3));
+            P.conv3(l23, Hd.rn[2], r2, B, nh, nw, ld[2], F, 1, rn_epi(r2r3));
+            P.conv3(l3, Hd.rn[3], r3, B, h3, w3, ld[3], F, 1, rn_epi(r3r3));      // l3 is bf3 in this mode
+            // refinement (dpt_head.py:57-60)
+            float* p4 = fusion_bf3(P, Hd.ref[3], r3, r3r3, nullptr, nullptr, false, B, h3, w3, F, nh, nw, false);
+            float* p3 = fusion_bf3(P, Hd.ref[2], p4, nullptr, r2, r2r3, true, B, nh, nw, F, 2 * nh, 2 * nw, false);
+            float* p2 = fusion_bf3(P, Hd.ref[1], p3, nullptr, r1, r1r3, true, B, 2 * nh, 2 * nw, F, 4 * nh, 4 * nw, false);
+            float* p13 = fusion_bf3(P, Hd.ref[0], p2, nullptr, r0, r0r3, true, B, 4 * nh, 4 * nw, F, 8 * nh, 8 * nw, true);
+            // head (dpt_block.py:323-330)
+            float* h0 = ar.alloc((size_t)B * Hh * Wh * (F / 2));
+            P.conv3(p13, Hd.h0w, h0, B, Hh, Wh, F, F / 2, 1, P.epi(A3R_EPI_NONE, Hd.h0b));
+            float* hu3 = P.alloc3((size_t)B * H * W, F / 2);
+            P.up3(h0, hu3, B, Hh, Wh, F / 2, H, W);
+            h2 = ar.alloc((size_t)B * H * W * L);
+            P.conv3(hu3, Hd.h2w, h2, B, H, W, F / 2, L, 1, P.epi(A3R_EPI_RELU, Hd.h2b));
+        }
         if (!P.skip())
             P.rc = a3r_head_final(h2, Hd.h4w, Hd.h4b, s ? pts2 : pts1, s ? conf2 : conf1, (long)B * H * W, L, stream);
     }

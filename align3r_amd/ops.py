@@ -65,9 +65,12 @@ def layernorm(x, w, b, eps=1e-6, out=None):
     return out
 
 
-def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False):
+def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
+                  aux_bf3=None, aux_relu=False):
     e = Epilogue()
     e.out_bf3 = int(out_bf3)
+    e.aux_bf3 = None if aux_bf3 is None else aux_bf3.data_ptr()
+    e.aux_relu = int(aux_relu)
     e.epi = kind
     e.bias = None if bias is None else bias.data_ptr()
     e.resid = None if resid is None else resid.data_ptr()
@@ -178,6 +181,22 @@ def linear_bf3_grouped(x3s, w3s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
     e = make_epilogue(epi, **kw)
     check(_lib.load().a3r_linear_bf3_grouped(arr, G, N, M, N, K, C.byref(e), stream_ptr()), "linear_bf3_grouped")
     return outs
+
+
+def conv3x3_bf3(x3: Bf3, wp3: Bf3, shape, bias=None, stride=1, epi=_lib.EPI_NONE, **kw):
+    """3x3 conv (padding 1) on the bf3 kernel: x3 = bf3 of the channels-last map `shape` = (B, H, W, Cin), wp3 = bf3 of the
+    packed weights [Cout, 9 Cin].  Returns fp32 [B, Ho, Wo, Cout] (or a Bf3 with out_bf3=True)."""
+    B, H, W, Cin = shape
+    Cout = wp3.rows
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    e = make_epilogue(epi, bias, **kw)
+    if e.out_bf3:
+        out = Bf3(torch.empty(B * Ho * Wo * Cout * 6, device=x3.data.device, dtype=torch.uint8), B * Ho * Wo, Cout)
+    else:
+        out = torch.empty((B, Ho, Wo, Cout), device=x3.data.device, dtype=torch.float32)
+    check(_lib.load().a3r_conv3x3_bf3(x3.data_ptr(), wp3.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, stride, C.byref(e),
+                                      stream_ptr()), "conv3x3_bf3")
+    return out
 
 
 def pack_conv3x3(w):

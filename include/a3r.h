@@ -95,6 +95,11 @@ typedef struct {
     /* a3r_linear_bf3 only: write y in bf3 form ([M][N/8][3][8] bf16, N % 8 == 0, ldc = N) instead of fp32, for outputs that
      * only feed the next bf3 GEMM (Mlp: fc1 + GELU -> fc2, blocks.py:73-77).  NONE / GELU / RELU epilogues. */
     int out_bf3;
+    /* bf3 kernels only: ALSO write the result (after bias / activation / residuals; through a ReLU if aux_relu) in bf3 form
+     * [M][N/8][3][8] to aux_bf3 -- the pre-activated input of the next 3x3 conv of a ResidualConvUnit, whose fp32 value is
+     * still needed for the skip connection (dpt_block.py:131-141). */
+    void* aux_bf3;
+    int aux_relu;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
@@ -141,6 +146,12 @@ typedef struct {
 int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int ldc, int M, int N, int K,
                            const a3r_epilogue* epi, void* stream);
 
+/* nn.Conv2d(k=3, padding=1, stride in {1,2}) as an implicit GEMM on the bf3 kernel: x3 = bf3 form of the channels-last map
+ * [B, H, W, Cin] (i.e. of the [B H W, Cin] matrix), wp3 = bf3 form of the packed weights [Cout, 9 Cin] (a3r_pack_conv3x3
+ * then a3r_split_bf3); y [B, Ho, Wo, Cout] fp32 (or bf3 with out_bf3).  Same call sites as a3r_conv3x3 (dpt_block.py). */
+int a3r_conv3x3_bf3(const void* x3, const void* wp3, float* y, int B, int H, int W, int Cin, int Cout, int stride,
+                    const a3r_epilogue* epi, void* stream);
+
 /* nn.Conv2d(k=3, padding=1, stride in {1,2}) on channels-last x [B, H, W, Cin] with PACKED weights
  * wp [Cout, 3, 3, Cin] (a3r_pack_conv3x3 from the checkpoint layout [Cout, Cin, 3, 3]); Cin % 32 == 0.
  * y [B, Ho, Wo, Cout].  Implicit GEMM on the same MFMA core.  (dpt_block.py:33-68,93-111,323-329,402-405) */
@@ -167,6 +178,8 @@ int a3r_patchify(const float* img, float* cols, int B, int C, int H, int W, long
 /* F.interpolate(scale_factor=2, bilinear, align_corners=True) on [B, H, W, C], writing only the
  * top-left Hc x Wc window of the 2H x 2W result (crop of dpt_head.py:57 folded in). C % 4 == 0. */
 int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
+/* the same, written in bf3 form ([B Hc Wc][C/8][3][8] bf16, C % 8 == 0): input of the next conv on the bf3 kernel */
+int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 
 /* last 1x1 conv (128 -> 4) + postprocess (dpt_block.py:329, postprocess.py:10-58):
  * x [P, C] -> pts3d [P, 3] = xyz/max(|xyz|,1e-8)*expm1(|xyz|), conf [P] = 1 + exp(c). */

@@ -125,3 +125,28 @@ def test_linear_bf3_argument_checks(ops):
         ops.linear_bf3(ops.split_bf3(rnd(64, 64, seed=1)), w3)
     with pytest.raises(RuntimeError, match="multiple of 8"):
         ops.split_bf3(rnd(4, 12, seed=1))
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 12, 16, 64, 64, 1), (1, 24, 32, 96, 256, 1), (2, 9, 7, 32, 128, 2),
+                                                    (1, 5, 5, 256, 64, 1), (1, 48, 64, 128, 128, 1)])
+def test_conv3x3_bf3_vs_float64(ops, monkeypatch, tile, B, H, W, Cin, Cout, stride):
+    """DPT-head 3x3 convs (dpt_block.py:33-142,323-329) as an implicit GEMM on the bf3 kernel, incl. padding and stride 2."""
+    from align3r_amd import _lib
+    monkeypatch.setenv("A3R_BF3_TILE", tile)
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=3)
+    x3 = ops.split_bf3(x)
+    wp3 = ops.split_bf3(ops.pack_conv3x3(w).reshape(Cout, 9 * Cin))
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    y = ops.conv3x3_bf3(x3, wp3, (B, H, W, Cin), b, stride=stride)
+    assert rel_err(cpu(y), cpu(ref)) < TOL
+    # ResidualConvUnit pieces: relu epilogue straight to bf3; residual epilogue + pre-activated bf3 side output
+    y3 = ops.conv3x3_bf3(x3, wp3, (B, H, W, Cin), b, stride=stride, epi=_lib.EPI_RELU, out_bf3=True)
+    assert torch.equal(y3.data, ops.split_bf3(torch.relu(y)).data)
+    r = rnd(*y.shape, seed=5)
+    aux = torch.zeros(y.numel() * 6, dtype=torch.uint8, device="cuda")
+    z = ops.conv3x3_bf3(x3, wp3, (B, H, W, Cin), b, stride=stride, epi=_lib.EPI_RESID, resid=r, aux_bf3=aux, aux_relu=True)
+    assert rel_err(cpu(z), cpu(ref + r.double())) < TOL
+    assert torch.equal(aux, ops.split_bf3(torch.relu(z)).data)
