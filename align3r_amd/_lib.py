@@ -79,6 +79,7 @@ SIGNATURES = {
     "a3r_pack_conv3x3": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void]),
     "a3r_pack_convT": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_attention": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_attention_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_rope_table_host": (C.c_int, [c_void, c_void, C.c_int, C.c_float]),
     "a3r_patchify": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, c_void]),
     "a3r_upsample2x": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),

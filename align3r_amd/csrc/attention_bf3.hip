@@ -1,0 +1,259 @@
+// Flash-style attention for head_dim 64 on the bf16 matrix cores, fp32-accurate ("bf3" operands, bf3.h).
+//
+// Replaces  attn = softmax(q @ k^T * hd^-0.5); x = attn @ v   of
+//   Attention.forward      croco/models/blocks.py:105-109
+//   CrossAttention.forward croco/models/blocks.py:164-168
+// like attention.hip, but both products run as six exact bf16 x bf16 MFMA passes over three-plane splits:
+//   * q, k, v arrive in bf3 form straight from the projection GEMM (RoPE + out_bf3 epilogue, gemm_bf3.hip);
+//   * S^T = K Q^T  (v_mfma_f32_32x32x16_bf16; a lane's K / Q operand is one 16-byte bf3 unit per plane);
+//   * online softmax in fp32 on the accumulators (a query is a lane, its keys sit in the registers);
+//   * P is split into three bf16 planes in registers (exactly: p = p0 + p1 + p2) and is directly the B operand of
+//     O^T = V^T P^T; V^T needs 8 consecutive KEYS per lane, so the V tile is staged through LDS transposed, with the
+//     keys of each 16-key step permuted to the order the S^T accumulator holds them (the contraction order is free);
+//   * O is written in bf3 form, the input format of the output projection GEMM.
+// A workgroup = 8 waves = 256 queries of one (batch, head), each wave 32 queries.  K tiles of 64 keys are prefetched by
+// LDS-DMA into a double buffer, V tiles global -> registers during the tile's MFMAs and scattered to LDS between two
+// barriers; inside a tile each 32-key block is a complete online-softmax step (one score accumulator live).
+// LDS images are conflict-free for ds_read_b128: K rows (24 units) rotate their units by (row >> 1) & 7; V^T rows
+// (8 units of 8 keys) XOR the unit index with (d >> 1) & 7.
+#include "common.h"
+#include "bf3.h"
+
+namespace a3r {
+
+constexpr int A3Q = 256;                    // queries per workgroup (8 waves x 32)
+constexpr int A3T = 512;                    // threads per workgroup
+constexpr int A3K = 64;                     // keys per tile
+constexpr int A3_KS_BYTES = A3K * 24 * 16;  // one K tile: 64 rows x 24 units (two of them: LDS-DMA double buffer)
+constexpr int A3_VT_BYTES = 3 * 64 * A3K * 2;   // V^T tile: 3 planes x 64 d x 64 keys (bf16)
+constexpr int A3_LDS_BYTES = 2 * A3_KS_BYTES + A3_VT_BYTES;   // 73,728 B
+
+struct Attn3Args {
+    const char *q, *k, *v;
+    char* o;
+    size_t pq, pk, pv, po;                  // row pitches in bytes (6 x leading dimension)
+    int B, H, Nq, Nk;
+};
+
+typedef const __attribute__((address_space(1))) void* a3_gptr;
+typedef __attribute__((address_space(3))) void* a3_lptr;
+
+__global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                // [2][64 rows][24 units]
+    char* Vt = smem + 2 * A3_KS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, half = lane >> 5;
+    // XCD-aware mapping (as attention.hip): all query blocks of one (batch, head) land on ONE XCD
+    const int nqb = (a.Nq + A3Q - 1) / A3Q;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int group = (seq / nqb) * 8 + xcd, qb = seq - (seq / nqb) * nqb;
+    if (group >= a.B * a.H) return;                 // uniform per workgroup
+    const int h = group % a.H, b = group / a.H;
+    const int q_row = qb * A3Q + wave * 32 + qi;
+    const int q_ld = q_row < a.Nq ? q_row : a.Nq - 1;
+
+    // Q operand (B of S^T = K Q^T): lane (query, half) holds, per 16-deep d-step s and plane p, unit (2 s + half) 3 + p
+    bf16x8 qf[4][3];
+    {
+        const char* qp = a.q + ((size_t)b * a.Nq + q_ld) * a.pq + h * 384;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) qf[s][p] = *reinterpret_cast<const bf16x8*>(qp + ((2 * s + half) * 3 + p) * 16);
+    }
+
+    // ---- staging: 1536 units of K and of V per tile, 3 + 3 per thread
+    // K: LDS-DMA, slot u = tid + 256 i = (row, c') is filled with source unit (c' + rot(row)) % 24 of key row
+    // V: through registers; unit u -> (key = u & 63, gp = u >> 6 = 3 kgroup + plane): a wave walks the keys of one (kgroup, plane)
+    const char* kbase = a.k + (size_t)b * a.Nk * a.pk + h * 384;
+    const char* vbase = a.v + (size_t)b * a.Nk * a.pv + h * 384;
+    auto issue_k = [&](int k0, int buf) {
+        char* base = Ks + buf * A3_KS_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int u = tid + A3T * i;
+            const int krow = u / 24, cp = u - krow * 24;
+            const int cu = (cp + ((krow >> 1) & 7)) % 24;
+            const int kk = min(k0 + krow, a.Nk - 1);              // keys past Nk: finite copies, masked to -inf below
+            __builtin_amdgcn_global_load_lds((a3_gptr)(kbase + (size_t)kk * a.pk + cu * 16), (a3_lptr)(base + A3T * 16 * i), 16, 0, 0);
+        }
+    };
+    u32x4 rv[3];
+    auto load_v = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int u = tid + A3T * i;
+            const int vkey = u & 63, gp = u >> 6;
+            const int vk = min(k0 + vkey, a.Nk - 1);
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)vk * a.pv + gp * 16);
+        }
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            // V^T scatter: key kk of the tile goes to position pos = 32 kt + 16 s2 + 8 hh + j with
+            // t = kk & 15: hh = (t >> 2) & 1, j = (t & 3) + 4 (t >> 3)   (the order the S^T accumulator holds its keys)
+            const int u = tid + A3T * i;
+            const int vkey = u & 63, gp = u >> 6, g = gp / 3, p = gp - 3 * g;
+            const int t = vkey & 15;
+            const int pos = (vkey & 48) + ((t >> 2) & 1) * 8 + (t & 3) + 4 * (t >> 3);
+            const int unit = pos >> 3, within = pos & 7;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int d = 8 * g + j;
+                const uint32_t w = rv[i][j >> 1];
+                const uint16_t val = (j & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffffu);
+                *reinterpret_cast<uint16_t*>(Vt + ((p * 64 + d) * 64 + ((unit ^ ((d >> 1) & 7)) * 8) + within) * 2) = val;
+            }
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) oacc[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float SCALE_LOG2E = 0.125f * 1.4426950408889634f;     // hd^-0.5 folded into the exp2 argument
+
+    const int krot = (qi >> 1) & 7;
+    const int ntiles = (a.Nk + A3K - 1) / A3K;
+    issue_k(0, 0);
+    load_v(0);
+    store_v();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int k0 = t * A3K;
+        if (t + 1 < ntiles) {
+            issue_k(k0 + A3K, (t + 1) & 1);        // that buffer was last read in iteration t-1: every wave has passed a barrier since
+            load_v(k0 + A3K);
+        }
+        const char* Kt = Ks + (t & 1) * A3_KS_BYTES;
+        // two 32-key blocks, each a full online-softmax step (keeps one score tile live at a time)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            // ---- S^T = K Q^T
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                bf16x8 kf[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const int c = ((2 * st + half) * 3 + p - krot + 24) % 24;
+                    kf[p] = *reinterpret_cast<const bf16x8*>(Kt + ((kb * 32 + qi) * 24 + c) * 16);
+                }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[st][0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][0], s, 0, 0, 0);
+            }
+            // ---- online softmax (keys of this lane: k0 + 32 kb + (e&3) + 8*(e>>2) + 4*half)
+            if (k0 + kb * 32 + 32 > a.Nk) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (key >= a.Nk) s[e] = -INFINITY;
+                }
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; e++) mx = fmaxf(mx, s[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);        // finite: block kb = 0 of every tile has a valid key, and m_run carries it on
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
+            m_run = m_new;
+            float lsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float p = __builtin_amdgcn_exp2f((s[e] - m_new) * SCALE_LOG2E);
+                s[e] = p;
+                lsum += p;
+            }
+            l_run = l_run * alpha + lsum;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) oacc[i][e] *= alpha;
+            // ---- O^T += V^T P^T: split P into planes (k-step s2 = accumulator elements 8 s2 .. 8 s2 + 7)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                u32x4 pf[3];
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) {
+                    uint32_t p0, p1, p2;
+                    bf3_split2(s[8 * s2 + 2 * mm], s[8 * s2 + 2 * mm + 1], p0, p1, p2);
+                    pf[0][mm] = p0; pf[1][mm] = p1; pf[2][mm] = p2;
+                }
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, pf[0]), b1 = __builtin_bit_cast(bf16x8, pf[1]),
+                             b2 = __builtin_bit_cast(bf16x8, pf[2]);
+                const int unit = kb * 4 + s2 * 2 + half;
+#pragma unroll
+                for (int db = 0; db < 2; db++) {
+                    const int d = db * 32 + qi;
+                    bf16x8 vf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; p++)
+                        vf[p] = *reinterpret_cast<const bf16x8*>(Vt + ((p * 64 + d) * 64 + ((unit ^ krot) * 8)) * 2);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], b0, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b1, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b2, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b0, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b1, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b0, oacc[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                       // every wave is done with this tile's V^T image
+        if (t + 1 < ntiles) store_v();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K DMAs for tile t+1 have landed
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.f / l_tot;
+    if (q_row < a.Nq) {
+        // lane (query, half) holds d = 32 db + 8 g + 4 half + (0..3): half a bf3 unit per plane
+        char* op = a.o + ((size_t)b * a.Nq + q_row) * a.po + h * 384;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = {oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l, oacc[db][4 * g + 2] * inv_l,
+                                 oacc[db][4 * g + 3] * inv_l};
+                bf3_store4(op, db * 32 + 8 * g + 4 * half, v);
+            }
+    }
+}
+
+}  // namespace a3r
+using namespace a3r;
+
+extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
+                                 int B, int H, int Nq, int Nk, void* stream) {
+    A3R_CHECK_ARG(q3 && k3 && v3 && o3, "a3r_attention_bf3: null pointer");
+    A3R_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "a3r_attention_bf3: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    A3R_CHECK_ARG(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ldo >= H * 64, "a3r_attention_bf3: row strides < H*64");
+    A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_bf3: row strides must be multiples of 8");
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q3) | reinterpret_cast<uintptr_t>(k3) | reinterpret_cast<uintptr_t>(v3) |
+                    reinterpret_cast<uintptr_t>(o3)) & 15) == 0, "a3r_attention_bf3: pointers must be 16-byte aligned");
+    static bool attr_done = false;
+    if (!attr_done) {
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    A3_LDS_BYTES));
+        attr_done = true;
+    }
+    Attn3Args a = {static_cast<const char*>(q3), static_cast<const char*>(k3), static_cast<const char*>(v3), static_cast<char*>(o3),
+                   (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk};
+    const int nqb = (Nq + A3Q - 1) / A3Q, groups = B * H;
+    dim3 grid(8 * ((groups + 7) / 8) * nqb);
+    ProfScope prof(PK_ATTENTION_BF3, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
+    hipLaunchKernelGGL(attn_bf3_kernel, grid, dim3(A3T), A3_LDS_BYTES, as_stream(stream), a);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}

@@ -177,8 +177,8 @@ static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char
     if (!e) return A3R_OK;
     if (e->out_bf3) {
         A3R_CHECK_ARG(bf3_kernel, "%s: out_bf3 is only available on the bf3 kernels", who);
-        A3R_CHECK_ARG(N % 8 == 0 && (e->epi == A3R_EPI_NONE || e->epi == A3R_EPI_GELU || e->epi == A3R_EPI_RELU),
-                      "%s: out_bf3 needs N %% 8 == 0 and a NONE / GELU / RELU epilogue", who);
+        A3R_CHECK_ARG(N % 8 == 0 && (e->epi == A3R_EPI_NONE || e->epi == A3R_EPI_GELU || e->epi == A3R_EPI_RELU || e->epi == A3R_EPI_ROPE),
+                      "%s: out_bf3 needs N %% 8 == 0 and a NONE / GELU / RELU / ROPE epilogue", who);
         A3R_CHECK_ARG(!e->aux_bf3, "%s: out_bf3 and aux_bf3 are exclusive", who);
     }
     if (e->aux_bf3) {

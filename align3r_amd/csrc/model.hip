@@ -384,6 +384,10 @@ struct Plan {
     float* gin_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
     float* gin_scratch(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : 0); }     // only needed for splitting
     template <class T> T* gin_at(T* base, size_t rows, int K) const { return base + (bf3() ? rows * K * 3 / 2 : rows * K); }
+    // column `col` (a multiple of 8) of a gin row
+    const float* gin_col(const float* base, int col) const {
+        return bf3() ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)col * 6) : base + col;
+    }
     // fp32 activation -> GEMM input: a split pass into `scratch` in bf3 mode, the array itself otherwise
     const float* gin_from(const float* x, float* scratch, long M, int K) {
         if (!bf3()) return x;
@@ -463,10 +467,12 @@ struct Plan {
         traced("layernorm_f32", M, D);
         rc = a3r_layernorm(x, w, b, y, M, D, 1e-6f, stream);
     }
+    // q, k, v, o are gin buffers (bf3 mode: straight from / to the projection GEMMs, no fp32 round trip)
     void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
         if (skip()) return;
         traced("attention", B, Nq, Nk);
-        rc = a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
+        rc = bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream)
+                   : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
     }
     void conv(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
         if (skip()) return;
@@ -478,22 +484,24 @@ struct Plan {
         traced("upsample2x", H, W, C);
         rc = a3r_upsample2x(x, y, B, H, W, C, Hc, Wc, stream);
     }
+    // projection feeding attention: RoPE on the leading columns, output in gin form
     a3r_epilogue rope_epi(const float* bias, int rope_cols, int ntok, int gw) {
         a3r_epilogue e = epi(A3R_EPI_ROPE, bias);
+        e.out_bf3 = bf3() ? 1 : 0;
         e.rope_cols = rope_cols; e.tokens_per_image = ntok; e.grid_w = gw;
         e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
         return e;
     }
 
     // Block.forward blocks.py:127-130 on x [M, D] in place (self-attention over images of ntok tokens)
-    // xn: gin [M, D]; att / hid: fp32; att3 / hid3: gin scratch of the same shapes
+    // xn [M, D], qkv [M, 3 D], att [M, D]: gin buffers
     void self_block(const BlockW& w, float* x, const float* resid_src, int M, int D, int H, int ntok, int gw, float* xn,
-                    float* qkv, float* att, float* att3) {
+                    float* qkv, float* att) {
         // x_out = resid_src + attn(LN1(resid_src)); then MLP in place on x
         ln(resid_src, w.n1w, w.n1b, xn, M, D);
         linear(xn, D, w.qkvw, qkv, 3 * D, M, 3 * D, D, rope_epi(w.qkvb, 2 * D, ntok, gw));
-        attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, M / ntok, H, ntok, ntok);
-        linear(gin_from(att, att3, M, D), D, w.projw, x, D, M, D, D, epi(A3R_EPI_RESID, w.projb, resid_src));
+        attn(qkv, 3 * D, gin_col(qkv, D), 3 * D, gin_col(qkv, 2 * D), 3 * D, att, D, M / ntok, H, ntok, ntok);
+        linear(att, D, w.projw, x, D, M, D, D, epi(A3R_EPI_RESID, w.projb, resid_src));
     }
     // hid: gin [M, hidden] -- fc1's GELU epilogue writes the GEMM-input form directly (Mlp blocks.py:73-77)
     a3r_epilogue gin_epi(int kind, const float* bias) {
@@ -601,9 +609,8 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* cols3 = P.gin_scratch(BN, 768);
         float* x = ar.alloc((size_t)BN * E);
         float* xn = P.gin_alloc(BN, E);
-        float* qkv = ar.alloc((size_t)BN * 3 * E);
-        float* att = ar.alloc((size_t)BN * E);
-        float* att3 = P.gin_scratch(BN, E);
+        float* qkv = P.gin_alloc(BN, 3 * E);
+        float* att = P.gin_alloc(BN, E);
         float* hid = P.gin_alloc(BN, E * c.mlp_ratio);
         if (!dry) {
             const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
@@ -611,7 +618,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         }
         P.linear(P.gin_from(cols, cols3, BN, 768), 768, m->pe_w, x, E, BN, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
         for (int i = 0; i < c.enc_depth; i++) {
-            P.self_block(m->enc[i], x, x, BN, E, c.enc_num_heads, N, nw, xn, qkv, att, att3);
+            P.self_block(m->enc[i], x, x, BN, E, c.enc_num_heads, N, nw, xn, qkv, att);
             P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, BN, E, E * c.mlp_ratio, xn, hid);
         }
         P.ln_f32(x, m->encn_w, m->encn_b, dry ? nullptr : feat_out, BN, E);
@@ -645,9 +652,8 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* cols3 = P.gin_scratch(M2, 768);
         float* x = ar.alloc((size_t)M2 * E);
         float* xn = P.gin_alloc(M2, E);
-        float* qkv = ar.alloc((size_t)M2 * 3 * E);
-        float* att = ar.alloc((size_t)M2 * E);
-        float* att3 = P.gin_scratch(M2, E);
+        float* qkv = P.gin_alloc(M2, 3 * E);
+        float* att = P.gin_alloc(M2, E);
         float* hid = P.gin_alloc(M2, E * c.mlp_ratio);
         if (!dry) {
             const long sb = 3L * H * W, sc = (long)H * W, sy = W, sx = 1;
@@ -656,7 +662,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         }
         P.linear(P.gin_from(cols, cols3, M2, 768), 768, m->pe_w, x, E, M2, E, 768, P.epi(A3R_EPI_NONE, m->pe_b));
         for (int i = 0; i < c.enc_depth; i++) {
-            P.self_block(m->enc[i], x, x, M2, E, c.enc_num_heads, N, nw, xn, qkv, att, att3);
+            P.self_block(m->enc[i], x, x, M2, E, c.enc_num_heads, N, nw, xn, qkv, att);
             P.mlp(m->enc[i], m->enc[i].n2w, m->enc[i].n2b, x, M2, E, E * c.mlp_ratio, xn, hid);
         }
         P.ln_f32(x, m->encn_w, m->encn_b, feat, M2, E);
@@ -676,11 +682,10 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         const int hidden = D * c.mlp_ratio;
         float* xn = P.gin_alloc(M2, D);
         float* yn = P.gin_alloc(M2, D);
-        float* qkv = ar.alloc((size_t)M2 * 3 * D);
-        float* qb = ar.alloc((size_t)M2 * D);
-        float* kv = ar.alloc((size_t)M2 * 2 * D);
-        float* att = ar.alloc((size_t)M2 * D);
-        float* att3 = P.gin_scratch(M2, D);
+        float* qkv = P.gin_alloc(M2, 3 * D);
+        float* qb = P.gin_alloc(M2, D);
+        float* kv = P.gin_alloc(M2, 2 * D);
+        float* att = P.gin_alloc(M2, D);
         float* hid = P.gin_alloc(M2, hidden);
         float* pc3 = P.gin_scratch(M2, D);
         float* cur = fbuf[0];
@@ -711,28 +716,23 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 float* yn1 = P.gin_at(yn, BN, D);
                 P.ln(x0, w0.n1w, w0.n1b, xn, BN, D);
                 P.ln(x1, w1.n1w, w1.n1b, xn1, BN, D);
-                P.linear2(xn, xn1, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, qkv + 3 * S, 3 * D, BN, 3 * D, D,
+                float* att1 = P.gin_at(att, BN, D);
+                P.linear2(xn, xn1, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, P.gin_at(qkv, BN, 3 * D), 3 * D, BN, 3 * D, D,
                           P.rope_epi(nullptr, 2 * D, N, nw));
-                P.attn(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, 2 * B, c.dec_num_heads, N, N);
-                {
-                    const float* ag = P.gin_from(att, att3, M2, D);
-                    P.linear2(ag, P.gin_at(ag, BN, D), D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
-                              P.epi(A3R_EPI_RESID, nullptr), x0, x1);
-                }
+                P.attn(qkv, 3 * D, P.gin_col(qkv, D), 3 * D, P.gin_col(qkv, 2 * D), 3 * D, att, D, 2 * B, c.dec_num_heads, N, N);
+                P.linear2(att, att1, D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
+                          P.epi(A3R_EPI_RESID, nullptr), x0, x1);
                 // y_ = norm_y(y); x = x + cross_attn(norm2(x), y_, y_)     blocks.py:188-189
                 P.ln(x1, w0.nyw, w0.nyb, yn, BN, D);               // side 0 attends to view 2's tokens
                 P.ln(x0, w1.nyw, w1.nyb, yn1, BN, D);
                 P.ln(o0, w0.n2w, w0.n2b, xn, BN, D);
                 P.ln(o1, w1.n2w, w1.n2b, xn1, BN, D);
-                P.linear2(xn, xn1, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, qb + S, D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
-                P.linear2(yn, yn1, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, kv + 2 * S, 2 * D, BN, 2 * D, D,
+                P.linear2(xn, xn1, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, P.gin_at(qb, BN, D), D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
+                P.linear2(yn, yn1, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, P.gin_at(kv, BN, 2 * D), 2 * D, BN, 2 * D, D,
                           P.rope_epi(nullptr, D, N, nw));
-                P.attn(qb, D, kv, 2 * D, kv + D, 2 * D, att, D, 2 * B, c.dec_num_heads, N, N);
-                {
-                    const float* ag = P.gin_from(att, att3, M2, D);
-                    P.linear2(ag, P.gin_at(ag, BN, D), D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
-                              P.epi(A3R_EPI_RESID, nullptr), o0, o1);
-                }
+                P.attn(qb, D, kv, 2 * D, P.gin_col(kv, D), 2 * D, att, D, 2 * B, c.dec_num_heads, N, N);
+                P.linear2(att, att1, D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
+                          P.epi(A3R_EPI_RESID, nullptr), o0, o1);
                 // x = x + mlp(norm3(x))                                    blocks.py:190
                 P.ln(o0, w0.n3w, w0.n3b, xn, BN, D);
                 P.ln(o1, w1.n3w, w1.n3b, xn1, BN, D);
@@ -743,7 +743,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                           P.epi(A3R_EPI_RESID, nullptr), o0, o1);
             }
             if (i < npc) {   // model.py:223-226
-                P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, xn, qkv, att, att3);
+                P.self_block(m->pc[i], pc, pc, M2, D, c.dec_num_heads, N, nw, xn, qkv, att);
                 P.mlp(m->pc[i], m->pc[i].n2w, m->pc[i].n2b, pc, M2, D, hidden, xn, hid);
                 P.linear(P.gin_from(pc, pc3, M2, D), D, m->zc_w[i + 1], nxt, D, M2, D, D, P.epi(A3R_EPI_RESID, m->zc_b[i + 1], nxt));
             }

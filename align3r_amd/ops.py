@@ -199,6 +199,15 @@ def conv3x3_bf3(x3: Bf3, wp3: Bf3, shape, bias=None, stride=1, epi=_lib.EPI_NONE
     return out
 
 
+def attention_bf3(q3: Bf3, k3: Bf3, v3: Bf3, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0) -> Bf3:
+    """softmax(q k^T / 8) v per head (head_dim 64) on bf3 operands; q3/k3/v3 may be column slices (start column, multiple of 8)
+    of wider bf3 matrices (e.g. the fused qkv projection).  Returns the bf3 [B*Nq, H*64] output."""
+    o3 = Bf3(torch.empty(B * Nq * H * 64 * 6, device=q3.data.device, dtype=torch.uint8), B * Nq, H * 64)
+    check(_lib.load().a3r_attention_bf3(q3.data_ptr() + q_col * 6, q3.K, k3.data_ptr() + k_col * 6, k3.K, v3.data_ptr() + v_col * 6, v3.K,
+                                        o3.data_ptr(), H * 64, B, H, Nq, Nk, stream_ptr()), "attention_bf3")
+    return o3
+
+
 def pack_conv3x3(w):
     Cout, Cin = w.shape[:2]
     wp = torch.empty((Cout, 3, 3, Cin), device=w.device, dtype=torch.float32)

@@ -93,7 +93,7 @@ typedef struct {
     /* PIXSHUF */
     int ps_s, ps_h, ps_w, ps_cout;  /* stride s, input map h x w, output channels */
     /* a3r_linear_bf3 only: write y in bf3 form ([M][N/8][3][8] bf16, N % 8 == 0, ldc = N) instead of fp32, for outputs that
-     * only feed the next bf3 GEMM (Mlp: fc1 + GELU -> fc2, blocks.py:73-77).  NONE / GELU / RELU epilogues. */
+     * only feed the next bf3 kernel (Mlp: fc1 + GELU -> fc2, blocks.py:73-77; qkv + RoPE -> attention).  NONE / GELU / RELU / ROPE. */
     int out_bf3;
     /* bf3 kernels only: ALSO write the result (after bias / activation / residuals; through a ReLU if aux_relu) in bf3 form
      * [M][N/8][3][8] to aux_bf3 -- the pre-activated input of the next 3x3 conv of a ResidualConvUnit, whose fp32 value is
@@ -165,6 +165,12 @@ int a3r_pack_convT(const float* w, float* wp, int Cin, int Cout, int s, void* st
  * q [B, Nq, ldq], k/v [B, Nk, ldk/ldv] with head h at column h*64; o [B, Nq, ldo].  q,k already rotated. */
 int a3r_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                   int B, int H, int Nq, int Nk, void* stream);
+/* The same attention on the bf16 matrix cores with fp32 accuracy: q3 / k3 / v3 / o3 are bf3 matrices (pointers to the first
+ * column's 48-byte group, leading dimensions in fp32 columns, multiples of 8); six exact bf16 MFMA passes per product,
+ * fp32 softmax, P split exactly into three planes in registers.  Consumes the RoPE + out_bf3 output of a3r_linear_bf3 and
+ * produces the bf3 input of the output projection. */
+int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
+                      int B, int H, int Nq, int Nk, void* stream);
 
 /* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
  * HOST buffers. */

@@ -150,3 +150,22 @@ def test_conv3x3_bf3_vs_float64(ops, monkeypatch, tile, B, H, W, Cin, Cout, stri
     z = ops.conv3x3_bf3(x3, wp3, (B, H, W, Cin), b, stride=stride, epi=_lib.EPI_RESID, resid=r, aux_bf3=aux, aux_relu=True)
     assert rel_err(cpu(z), cpu(ref + r.double())) < TOL
     assert torch.equal(aux, ops.split_bf3(torch.relu(z)).data)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 32, 64), (2, 3, 196, 196), (1, 2, 768, 768), (2, 2, 100, 37), (1, 12, 576, 576), (1, 1, 300, 65)])
+def test_attention_bf3(ops, B, H, Nq, Nk):
+    """softmax(q k^T / 8) v on bf3 operands (blocks.py:105-109,164-168) vs float64, fused-qkv column slices included."""
+    D = H * 64
+    q, k, v = rnd(B * Nq, D, seed=1), rnd(B * Nk, D, seed=2), rnd(B * Nk, D, seed=3)
+    qd, kd, vd = (t.double().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / 8.0, -1) @ vd).transpose(1, 2).reshape(B * Nq, D)
+    o3 = ops.attention_bf3(ops.split_bf3(q), ops.split_bf3(k), ops.split_bf3(v), B, H, Nq, Nk)
+    got = o3.planes().double().sum(0)
+    assert rel_err(cpu(got), cpu(ref)) < TOL
+    if Nq == Nk:      # the self-attention layout: one [rows, 3 D] bf3 matrix, q / k / v are column slices
+        qkv3 = ops.split_bf3(torch.cat([q, k, v], 1).contiguous())
+        o3b = ops.attention_bf3(qkv3, qkv3, qkv3, B, H, Nq, Nk, q_col=0, k_col=D, v_col=2 * D)
+        assert torch.equal(o3b.data, o3.data)
+    # the output is a valid bf3 matrix of the fp32-rounded result: planes are non-overlapping
+    p = o3.planes()
+    assert float((p[1].abs() > p[0].abs() * 2.0 ** -7 + 1e-38).sum()) == 0
