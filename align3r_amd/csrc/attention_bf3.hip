@@ -177,10 +177,12 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
                 lsum += p;
             }
             l_run = l_run * alpha + lsum;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {          // the running max moved for some query of this wave (rare after the first tiles)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+                for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) oacc[i][e] *= alpha;
+                    for (int e = 0; e < 16; e++) oacc[i][e] *= alpha;
+            }
             // ---- O^T += V^T P^T: split P into planes (k-step s2 = accumulator elements 8 s2 .. 8 s2 + 7)
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {

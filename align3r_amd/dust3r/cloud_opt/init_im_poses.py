@@ -67,10 +67,29 @@ def estimate_focal(pts3d_i):
 
 def linear_pnp(pts3d, focal, msk, pp=None, irls_rounds=2):
     """Camera-to-world pose of an image whose pixels see the world points pts3d [H,W,3] (stands in for fast_pnp :442-482).
-    Direct linear transform on the calibrated rays, Procrustes projection of the 3x3 block, IRLS on the ray residual."""
+    Direct linear transform on the calibrated rays, Procrustes projection of the 3x3 block, IRLS on the ray residual.
+    focal=None (an image that is never the first view of an edge, e.g. the last frame of a non-symmetrised graph): like
+    fast_pnp, try 21 focals in geomspace(S/2, 3S) and keep the one with most inliers (reprojection error < 5 px)."""
     H, W, _ = pts3d.shape
     if int(msk.sum()) < 6:
         return None
+    if focal is None:
+        best = None
+        for f in np.geomspace(max(W, H) / 2, max(W, H) * 3, 21):
+            res = linear_pnp(pts3d, float(f), msk, pp=pp, irls_rounds=irls_rounds)
+            if res is None:
+                continue
+            c2w = res[1]
+            w2c = torch.linalg.inv(c2w.double())
+            cam = pts3d[msk].double() @ w2c[:3, :3].T + w2c[:3, 3]
+            ys, xs = torch.meshgrid(torch.arange(H, device=pts3d.device), torch.arange(W, device=pts3d.device), indexing='ij')
+            c = (W / 2, H / 2) if pp is None else pp
+            px = torch.stack((xs[msk] - c[0], ys[msk] - c[1]), -1).double()
+            err = (f * cam[:, :2] / cam[:, 2:3].clamp(min=1e-9) - px).norm(dim=-1)
+            score = int(((err < 5) & (cam[:, 2] > 0)).sum())
+            if best is None or score > best[0]:
+                best = (score, float(f), c2w)
+        return None if best is None or best[0] == 0 else (best[1], best[2])
     dev = pts3d.device
     ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
     pp = (W / 2, H / 2) if pp is None else pp

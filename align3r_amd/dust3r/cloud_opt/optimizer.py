@@ -230,6 +230,41 @@ class PointCloudOptimizer:
         trf = self.conf_trf if mode is None else get_conf_trf(mode)
         return [trf(c) for c in self.im_conf]
 
+    # ------------------------------------------------------------------ output files (base_opt.py:279-343)
+    def get_tum_poses(self):
+        from ...tool.hierarchical import get_tum_poses
+        return get_tum_poses(self.get_im_poses())
+
+    def save_tum_poses(self, path):
+        from ...tool.hierarchical import save_trajectory_tum_format
+        traj = self.get_tum_poses()
+        save_trajectory_tum_format(traj, path)
+        return traj[0]
+
+    def save_focals(self, path):
+        focals = self.get_focals()
+        np.savetxt(path, focals.detach().cpu().numpy(), fmt='%.6f')
+        return focals
+
+    def save_intrinsics(self, path):
+        from ...tool.hierarchical import save_intrinsics
+        K = self.get_intrinsics()
+        save_intrinsics(K, path)
+        return K
+
+    def save_conf_maps(self, path, start=0):
+        from ...tool.hierarchical import save_frame_arrays
+        conf = self.get_conf()
+        save_frame_arrays(conf, path, 'conf_{}.npy', start)
+        return conf
+
+    def save_depth_maps(self, path, start=0):
+        """frame_XXXX.npy per image (the reference also writes JET-coloured PNGs and a GIF through cv2: not available)."""
+        from ...tool.hierarchical import save_frame_arrays
+        depth_maps = self.get_depthmaps()
+        save_frame_arrays(depth_maps, path, 'frame_{:04d}.npy', start)
+        return depth_maps
+
     def get_masks(self):
         return [(conf > self.min_conf_thr) for conf in self.im_conf]
 

@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only -- /root/reference does not exist on the GPU box):
-    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow] [--out tests/golden]
+    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow|prep|hier] [--out tests/golden]
 
 What it does
   * puts /root/reference on sys.path (read-only, bytecode writing disabled) and imports the
@@ -522,6 +522,89 @@ def gen_alignflow(out):
         json.dump(meta, f)
 
 
+# ----------------------------------------------------------------------------- N3 preprocessing / N2 driver pieces
+def _ref_function(path, name, glb):
+    """Compile ONE top-level function of a reference file (its module cannot be imported here: tool/depth_test.py pulls in
+    third-party models at import time) and return it bound to the globals `glb`."""
+    import ast
+    src = open(os.path.join(REF, path)).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            code = compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF, path), "exec")
+            exec(code, glb)
+            return glb[name]
+    raise KeyError(name)
+
+
+def gen_prep(out):
+    """dust3r/utils/image_pose.py: the PIL / numpy part of load_images (crop_img without a point map, pixel_to_pointcloud,
+    normalize_pointcloud, crop_center, _resize_pil_image).  cv2 is a stub here, so resize_numpy_image is NOT exercised."""
+    import PIL.Image
+    from dust3r.utils import image_pose as ref
+    rng = np.random.RandomState(7)
+    cases, arrays = [], {}
+    for k, (w, h, size, square_ok, crop) in enumerate([(640, 480, 512, False, True), (1024, 436, 512, False, True), (300, 500, 224, False, True),
+                                                        (512, 512, 512, True, True), (200, 150, 512, False, True), (854, 480, 512, False, False),
+                                                        (640, 480, 224, False, True)]):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        pil = PIL.Image.fromarray(img)
+        got, _ = ref.crop_img(pil, size, square_ok=square_ok, crop=crop)
+        # inputs are regenerable (RandomState(7), same call order); outputs are pinned by hash + a strided sample
+        got_arr = np.array(got)
+        arrays[f"crop{k}_sample"] = got_arr[::16, ::16]
+        cases.append(dict(w=w, h=h, size=size, square_ok=square_ok, crop=crop, out_size=list(got.size),
+                          sha256=hashlib.sha256(got_arr.tobytes()).hexdigest()))
+    depth = (rng.rand(37, 53).astype(np.float32) * 5 + 0.5)
+    arrays["depth"] = depth
+    arrays["pointcloud"] = ref.pixel_to_pointcloud(depth, np.float32(311.5))
+    arrays["pointcloud_f64"] = ref.pixel_to_pointcloud(depth.astype(np.float64), 200)
+    arr = rng.rand(41, 58, 3).astype(np.float32)
+    arrays["cc_in"] = arr
+    arrays["cc_out"] = ref.crop_center(arr, 32, 16)
+    arrays["cc_out2"] = ref.crop_center(arr, 100, 30)
+    np.savez_compressed(os.path.join(out, "prep.npz"), **arrays)
+    json.dump(dict(cases=cases, note="crop_img on PIL images (no point map), pixel_to_pointcloud, crop_center from the reference"),
+              open(os.path.join(out, "prep.json"), "w"), indent=1)
+    print("prep:", len(cases), "crop cases")
+
+
+def gen_hier(out):
+    """tool/depth_test.py my_make_pairs (+ the clip-size rule, evaluated inline) and cloud_opt/base_opt.py c2w_to_tumpose."""
+    mk = _ref_function("tool/depth_test.py", "my_make_pairs", {})
+    from dust3r.cloud_opt.base_opt import c2w_to_tumpose
+    cases = []
+    for n, cs in [(7, 3), (10, 4), (23, 10), (5, 2), (12, 5), (50, 49)]:
+        imgs = [dict(idx=i, instance=f"f{i}") for i in range(n)]
+        coarse, kf, clips, ids = mk(imgs, cs)
+        cases.append(dict(n=n, clip_size=cs, keyframes_id=kf, all_clips_id=ids,
+                          coarse=[[a["instance"], a["idx"], b["instance"], b["idx"]] for a, b in coarse],
+                          clips=[[[a["instance"], a["idx"], b["instance"], b["idx"]] for a, b in cl] for cl in clips],
+                          idx_after=[v["idx"] for v in imgs]))
+    rule = []
+    for n in list(range(3, 60)) + [110, 151, 200]:
+        for start in (10, 50):
+            cs = start
+            try:
+                while n % cs == 1 or n % cs == 0 or cs > n:      # depth_test.py:637-638 / demo.py:194-195
+                    cs -= 1
+            except ZeroDivisionError:                            # the reference's loop runs off the end for these n
+                cs = None
+            rule.append([n, start, cs])
+    rng = np.random.RandomState(3)
+    poses, tum = [], []
+    for _ in range(12):
+        q = rng.randn(4); q /= np.linalg.norm(q)
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        P = np.eye(4); P[:3, :3] = R; P[:3, 3] = rng.randn(3)
+        poses.append(P.astype(np.float32).tolist())
+        tum.append(c2w_to_tumpose(torch.tensor(P, dtype=torch.float32)).tolist())
+    json.dump(dict(make_pairs=cases, clip_rule=rule, poses=poses, tum=tum), open(os.path.join(out, "hier.json"), "w"))
+    print("hier:", len(cases), "pair cases,", len(rule), "clip-size cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -529,7 +612,9 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(8)
     todo = [a.only] if a.only else ["pairs", "ops", "tiny", "vitl", "align", "alignflow"]
-    import_reference(aligner=any(t.startswith("align") for t in todo))
+    import_reference(aligner=any(t.startswith("align") or t in ("prep", "hier") for t in todo))
+    if "prep" in todo:
+        _stub("imageio")
     for t in todo:
         globals()[f"gen_{t}"](a.out)
 

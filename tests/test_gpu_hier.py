@@ -1,0 +1,97 @@
+"""GPU: the hierarchical keyframe -> clip driver (tool/depth_test.py:628-676) end to end.
+
+The pair forward is replaced by a synthetic, geometrically consistent pointmap generator (a TINY random-weight model cannot
+produce consistent geometry), so the test pins what the driver adds: clip cutting, the keyframe pass, `init_priors` chaining
+(every clip must land in the keyframes' world frame) and the output files.  MST init is parity-unpinned (roma / cv2 absent)
+and is validated by its purpose, as in test_gpu_api.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(N, H, W):
+    f = 1.2 * max(H, W)
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    rays = np.stack([(xs - W / 2) / f, (ys - H / 2) / f, np.ones_like(xs)], -1)
+    cams, world = [], []
+    for n in range(N):
+        a = 0.05 * n
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        t = np.array([0.2 * n, 0.03 * n, 0.01 * n])
+        d = 3 + 0.8 * np.sin(xs / W * 5 + 0.3 * n) * np.cos(ys / H * 4)
+        cams.append((R, t))
+        world.append((rays * d[..., None]) @ R.T + t)
+    return cams, world, f
+
+
+def test_hierarchical_alignment_chains_clips_into_the_keyframe_frame(monkeypatch, tmp_path):
+    import align3r_amd.dust3r.inference as inf_mod
+    from align3r_amd.tool import hierarchical as hz
+    N, H, W = 8, 32, 48
+    cams, world, f = _scene(N, H, W)
+    rng = np.random.default_rng(0)
+
+    def fake_inference(pairs, model, device, batch_size=1, verbose=False):
+        gi = [int(a["instance"]) for a, b in pairs]
+        gj = [int(b["instance"]) for a, b in pairs]
+        p1 = np.stack([0.7 * ((world[i] - cams[i][1]) @ cams[i][0]) for i in gi]).astype(np.float32)
+        p2 = np.stack([0.7 * ((world[j] - cams[i][1]) @ cams[i][0]) for i, j in zip(gi, gj)]).astype(np.float32)
+        p1 += 0.001 * rng.standard_normal(p1.shape).astype(np.float32)
+        p2 += 0.001 * rng.standard_normal(p2.shape).astype(np.float32)
+        c = (2 + 8 * rng.random((len(pairs), H, W))).astype(np.float32)
+        return dict(view1=dict(idx=[a["idx"] for a, b in pairs]), view2=dict(idx=[b["idx"] for a, b in pairs]),
+                    pred1=dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c)),
+                    pred2=dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c.copy())))
+
+    monkeypatch.setattr(inf_mod, "inference", fake_inference)
+    imgs = [dict(idx=i, instance=str(i), true_shape=np.int32([[H, W]])) for i in range(N)]
+    torch.manual_seed(0)
+    res = hz.hierarchical_alignment(imgs, None, "cuda", clip_size=3, niter=30, schedule="linear", lr=0.01, min_conf_thr=1.5,
+                                    output_dir=str(tmp_path))
+    assert res["clip_size"] == 3 and res["keyframes_id"] == [0, 3, 6]
+    assert len(res["depths"]) == N and len(res["poses"]) == N and len(res["confs"]) == N and len(res["focals"]) == N
+    assert all(np.isfinite(d).all() and d.shape == (H, W) for d in res["depths"])
+    # frames that are never the first view of an edge (the last frame of each non-symmetrised clip) get their focal from the
+    # 21-step geometric search of fast_pnp (steps of ~9 %), then 30 iterations of refinement: coarse, as in the reference
+    assert np.all(np.abs(np.array(res["focals"]) / f - 1) < 0.2), res["focals"]
+    assert int((np.abs(np.array(res["focals"]) / f - 1) < 0.02).sum()) >= N // 2
+    # rotations: all frames in ONE world frame (the keyframes').  Translations: the reference chains pose and focal of the
+    # keyframe into its clip, not the depth, so every clip keeps its own (normalised) scale -- inside a clip the baselines
+    # must be parallel to the truth and proportional to it.
+    poses = np.array(res["poses"], np.float64)
+
+    def truth(a, b):
+        Ta, Tb = np.eye(4), np.eye(4)
+        Ta[:3, :3], Ta[:3, 3] = cams[a]
+        Tb[:3, :3], Tb[:3, 3] = cams[b]
+        return np.linalg.inv(Ta) @ Tb
+
+    for n in range(1, N):
+        rel = np.linalg.inv(poses[0]) @ poses[n]
+        assert np.abs(rel[:3, :3] - truth(0, n)[:3, :3]).max() < 0.03, n
+    for k in res["keyframes_id"]:
+        frames = [n for n in range(k + 1, min(k + res["clip_size"], N))]
+        ratios = []
+        for n in frames:
+            rel, gt = np.linalg.inv(poses[k]) @ poses[n], truth(k, n)
+            cosang = rel[:3, 3] @ gt[:3, 3] / (np.linalg.norm(rel[:3, 3]) * np.linalg.norm(gt[:3, 3]))
+            assert cosang > (0.98 if abs(res["focals"][n] / f - 1) < 0.02 else 0.85), (k, n, cosang)
+            ratios.append(np.linalg.norm(rel[:3, 3]) / np.linalg.norm(gt[:3, 3]))
+        if len(ratios) > 1:
+            assert max(ratios) / min(ratios) < 1.5, (k, ratios)
+    # the first frame of every clip sits where the keyframe pass put it (init_priors), up to the clip's own refinement
+    kp = res["key_scene"].get_im_poses().cpu().numpy()
+    for c, k in enumerate(res["keyframes_id"]):
+        assert np.abs(poses[k][:3, :3] - kp[c][:3, :3]).max() < 0.05
+    # files (demo.py:225-243)
+    lines = (tmp_path / "pred_traj.txt").read_text().splitlines()
+    assert len(lines) == N and all(len(ln.split()) == 8 for ln in lines)
+    assert len((tmp_path / "pred_intrinsics.txt").read_text().splitlines()) == N
+    assert sorted(p.name for p in tmp_path.glob("frame_*.npy")) == [f"frame_{i:04d}.npy" for i in range(N)]
+    assert np.array_equal(np.load(tmp_path / "frame_0004.npy"), res["depths"][4])
+    assert len(list(tmp_path.glob("conf_*.npy"))) == N
+    with pytest.raises(ValueError, match="at least 3 frames"):
+        hz.hierarchical_alignment(imgs[:2], None, "cuda")
