@@ -101,3 +101,25 @@ def test_shape_errors(tiny_engine):
         tiny_engine.forward(z(1, 3, 40, 64), z(1, 3, 40, 64), z(1, 40, 64, 3), z(1, 40, 64, 3))
     with pytest.raises(RuntimeError):
         tiny_engine.forward(z(1, 3, 64, 64), z(1, 3, 64, 64), z(1, 3, 64, 64), z(1, 64, 64, 3))
+
+
+def test_exact_fp32_mfma_path_still_matches(monkeypatch):
+    """A3R_GEMM=f32 runs the same plan on the exact-fp32 MFMA kernels (gemm.hip / attention.hip): both arithmetic paths stay
+    pinned to the reference golden, and they agree with each other far inside the tolerance."""
+    from align3r_amd.engine import PairEngine
+    t = np.load(os.path.join(GOLDEN, "tiny_e2e.npz"))
+    H, W = 64, 96
+    v = make_view_arrays(2, H, W)
+    img1, img2 = np.concatenate([v[1][0], v[0][0]]), np.concatenate([v[0][0], v[1][0]])
+    pd1, pd2 = np.concatenate([v[1][1], v[0][1]]), np.concatenate([v[0][1], v[1][1]])
+    monkeypatch.setenv("A3R_GEMM", "f32")
+    eng32 = PairEngine(TINY, synthetic_state_dict(TINY, 0))
+    monkeypatch.delenv("A3R_GEMM")
+    eng3 = PairEngine(TINY, synthetic_state_dict(TINY, 0))
+    assert eng32.lib.a3r_model_packed_bytes(eng32.handle) < eng3.lib.a3r_model_packed_bytes(eng3.handle)   # no bf3 twins in f32 mode
+    r32 = eng32.forward(*to_dev(img1, img2, pd1, pd2))
+    r3 = eng3.forward(*to_dev(img1, img2, pd1, pd2))
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        assert rel_err(host(r32[k]), t[f"a_{k}"]) < TOL, k
+        assert rel_err(host(r3[k]), t[f"a_{k}"]) < TOL, k
+        assert rel_err(host(r3[k]), host(r32[k])) < 2e-5, k
