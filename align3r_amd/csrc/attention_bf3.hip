@@ -14,8 +14,7 @@
 // A workgroup = 8 waves = 256 queries of one (batch, head), each wave 32 queries.  K tiles of 64 keys are prefetched by
 // LDS-DMA into a double buffer, V tiles global -> registers during the tile's MFMAs and scattered to LDS between two
 // barriers; inside a tile each 32-key block is a complete online-softmax step (one score accumulator live).
-// LDS images are conflict-free for ds_read_b128: K rows (24 units) rotate their units by (row >> 1) & 7; V^T rows
-// (8 units of 8 keys) XOR the unit index with (d >> 1) & 7.
+// LDS images are conflict-free for ds_read_b128 by padding: K rows are 24 + 1 units, V^T rows 8 + 1 units (odd strides).
 #include "common.h"
 #include "bf3.h"
 
@@ -24,9 +23,13 @@ namespace a3r {
 constexpr int A3Q = 256;                    // queries per workgroup (8 waves x 32)
 constexpr int A3T = 512;                    // threads per workgroup
 constexpr int A3K = 64;                     // keys per tile
-constexpr int A3_KS_BYTES = A3K * 24 * 16;  // one K tile: 64 rows x 24 units (two of them: LDS-DMA double buffer)
-constexpr int A3_VT_BYTES = 3 * 64 * A3K * 2;   // V^T tile: 3 planes x 64 d x 64 keys (bf16)
-constexpr int A3_LDS_BYTES = 2 * A3_KS_BYTES + A3_VT_BYTES;   // 73,728 B
+// LDS images are padded by one 16-byte unit per row (K: 24 + 1 units, V^T: 8 + 1): an odd row stride in units makes every
+// ds_read_b128 of an MFMA operand conflict-free with plain immediate offsets (no per-lane swizzle arithmetic).
+constexpr int A3_KROW = 25 * 16;            // K row: 24 units + 1 pad unit (the pad is DMA'd too: LDS-DMA writes lane-linear)
+constexpr int A3_KS_BYTES = A3K * A3_KROW;  // one K tile (two of them: LDS-DMA double buffer)
+constexpr int A3_VROW = 9 * 16;             // V^T row: 64 keys x 2 B + 1 pad unit
+constexpr int A3_VT_BYTES = 3 * 64 * A3_VROW;   // V^T tile: 3 planes x 64 d
+constexpr int A3_LDS_BYTES = 2 * A3_KS_BYTES + A3_VT_BYTES;   // 78,848 B
 
 struct Attn3Args {
     const char *q, *k, *v;
@@ -64,48 +67,49 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
             for (int p = 0; p < 3; p++) qf[s][p] = *reinterpret_cast<const bf16x8*>(qp + ((2 * s + half) * 3 + p) * 16);
     }
 
-    // ---- staging: 1536 units of K and of V per tile, 3 + 3 per thread
-    // K: LDS-DMA, slot u = tid + 256 i = (row, c') is filled with source unit (c' + rot(row)) % 24 of key row
-    // V: through registers; unit u -> (key = u & 63, gp = u >> 6 = 3 kgroup + plane): a wave walks the keys of one (kgroup, plane)
+    // ---- staging
+    // K: LDS-DMA of 64 x 25 = 1600 slots (3 per thread + one more on wave 0); slot u = (row u / 25, unit u % 25), the pad
+    //    unit re-reads unit 0.  V: 1536 units through registers, 3 per thread; unit u -> (key = u & 63 = tid & 63,
+    //    gp = u >> 6 = 3 kgroup + plane): a wave walks the keys of one (kgroup, plane).
     const char* kbase = a.k + (size_t)b * a.Nk * a.pk + h * 384;
     const char* vbase = a.v + (size_t)b * a.Nk * a.pv + h * 384;
+    int krow_[4], kcu_[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = min(tid + A3T * i, 1599);
+        krow_[i] = u / 25;
+        const int cu = u - krow_[i] * 25;
+        kcu_[i] = (cu == 24 ? 0 : cu) * 16;
+    }
     auto issue_k = [&](int k0, int buf) {
         char* base = Ks + buf * A3_KS_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int u = tid + A3T * i;
-            const int krow = u / 24, cp = u - krow * 24;
-            const int cu = (cp + ((krow >> 1) & 7)) % 24;
-            const int kk = min(k0 + krow, a.Nk - 1);              // keys past Nk: finite copies, masked to -inf below
-            __builtin_amdgcn_global_load_lds((a3_gptr)(kbase + (size_t)kk * a.pk + cu * 16), (a3_lptr)(base + A3T * 16 * i), 16, 0, 0);
+        for (int i = 0; i < 4; i++) {
+            if (i == 3 && wave != 0) break;                       // slots 1536..1599: one wave
+            const int kk = min(k0 + krow_[i], a.Nk - 1);          // keys past Nk: finite copies, masked to -inf below
+            __builtin_amdgcn_global_load_lds((a3_gptr)(kbase + (size_t)kk * a.pk + kcu_[i]), (a3_lptr)(base + A3T * 16 * i), 16, 0, 0);
         }
     };
+    // V^T position of this thread's key: pos = 32 kt + 16 s2 + 8 hh + j with t = key & 15: hh = (t >> 2) & 1,
+    // j = (t & 3) + 4 (t >> 3)   (the order the S^T accumulator holds its keys)
+    const int vkey = tid & 63, vt = vkey & 15;
+    const int vpos2 = ((vkey & 48) + ((vt >> 2) & 1) * 8 + (vt & 3) + 4 * (vt >> 3)) * 2;
     u32x4 rv[3];
     auto load_v = [&](int k0) {
+        const int vk = min(k0 + vkey, a.Nk - 1);
+        const char* src = vbase + (size_t)vk * a.pv + wave * 16;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int u = tid + A3T * i;
-            const int vkey = u & 63, gp = u >> 6;
-            const int vk = min(k0 + vkey, a.Nk - 1);
-            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)vk * a.pv + gp * 16);
-        }
+        for (int i = 0; i < 3; i++) rv[i] = *reinterpret_cast<const u32x4*>(src + 128 * i);      // gp = wave + 8 i
     };
     auto store_v = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            // V^T scatter: key kk of the tile goes to position pos = 32 kt + 16 s2 + 8 hh + j with
-            // t = kk & 15: hh = (t >> 2) & 1, j = (t & 3) + 4 (t >> 3)   (the order the S^T accumulator holds its keys)
-            const int u = tid + A3T * i;
-            const int vkey = u & 63, gp = u >> 6, g = gp / 3, p = gp - 3 * g;
-            const int t = vkey & 15;
-            const int pos = (vkey & 48) + ((t >> 2) & 1) * 8 + (t & 3) + 4 * (t >> 3);
-            const int unit = pos >> 3, within = pos & 7;
+            const int gp = wave + 8 * i, g = gp / 3, p = gp - 3 * g;                               // wave-uniform
+            char* dst = Vt + (p * 64 + 8 * g) * A3_VROW + vpos2;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const int d = 8 * g + j;
                 const uint32_t w = rv[i][j >> 1];
-                const uint16_t val = (j & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffffu);
-                *reinterpret_cast<uint16_t*>(Vt + ((p * 64 + d) * 64 + ((unit ^ ((d >> 1) & 7)) * 8) + within) * 2) = val;
+                *reinterpret_cast<uint16_t*>(dst + j * A3_VROW) = (j & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffffu);
             }
         }
     };
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
     float m_run = -INFINITY, l_run = 0.f;
     const float SCALE_LOG2E = 0.125f * 1.4426950408889634f;     // hd^-0.5 folded into the exp2 argument
 
-    const int krot = (qi >> 1) & 7;
+    const int kfrag = qi * A3_KROW + half * 48;       // this lane's K operand: row qi (+32 kb), units (2 st + half) 3 + p
+    const int vfrag = qi * A3_VROW + half * 16;       // this lane's V^T operand: row d = qi (+32 db), unit 4 kb + 2 s2 + half
     const int ntiles = (a.Nk + A3K - 1) / A3K;
     issue_k(0, 0);
     load_v(0);
@@ -143,10 +148,8 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
             for (int st = 0; st < 4; st++) {
                 bf16x8 kf[3];
 #pragma unroll
-                for (int p = 0; p < 3; p++) {
-                    const int c = ((2 * st + half) * 3 + p - krot + 24) % 24;
-                    kf[p] = *reinterpret_cast<const bf16x8*>(Kt + ((kb * 32 + qi) * 24 + c) * 16);
-                }
+                for (int p = 0; p < 3; p++)
+                    kf[p] = *reinterpret_cast<const bf16x8*>(Kt + kfrag + kb * 32 * A3_KROW + st * 96 + p * 16);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[st][0], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][1], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][2], s, 0, 0, 0);
@@ -195,14 +198,12 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
                 }
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, pf[0]), b1 = __builtin_bit_cast(bf16x8, pf[1]),
                              b2 = __builtin_bit_cast(bf16x8, pf[2]);
-                const int unit = kb * 4 + s2 * 2 + half;
 #pragma unroll
                 for (int db = 0; db < 2; db++) {
-                    const int d = db * 32 + qi;
                     bf16x8 vf[3];
 #pragma unroll
                     for (int p = 0; p < 3; p++)
-                        vf[p] = *reinterpret_cast<const bf16x8*>(Vt + ((p * 64 + d) * 64 + ((unit ^ krot) * 8)) * 2);
+                        vf[p] = *reinterpret_cast<const bf16x8*>(Vt + vfrag + (p * 64 + db * 32) * A3_VROW + (kb * 4 + s2 * 2) * 16);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], b0, oacc[db], 0, 0, 0);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b1, oacc[db], 0, 0, 0);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b2, oacc[db], 0, 0, 0);
