@@ -11,7 +11,7 @@
 //     O^T = V^T P^T; V^T needs 8 consecutive KEYS per lane, so the V tile is staged through LDS transposed, with the
 //     keys of each 16-key step permuted to the order the S^T accumulator holds them (the contraction order is free);
 //   * O is written in bf3 form, the input format of the output projection GEMM.
-// A workgroup = 8 waves = 256 queries of one (batch, head), each wave 32 queries.  K tiles of 64 keys are prefetched by
+// A workgroup = 4 waves = 128 queries of one (batch, head), each wave 32 queries; two workgroups share a CU.  K tiles of 64 keys are prefetched by
 // LDS-DMA into a double buffer, V tiles global -> registers during the tile's MFMAs and scattered to LDS between two
 // barriers; inside a tile each 32-key block is a complete online-softmax step (one score accumulator live).
 // LDS images are conflict-free for ds_read_b128 by padding: K rows are 24 + 1 units, V^T rows 8 + 1 units (odd strides).
@@ -20,8 +20,13 @@
 
 namespace a3r {
 
-constexpr int A3Q = 256;                    // queries per workgroup (8 waves x 32)
-constexpr int A3T = 512;                    // threads per workgroup
+#ifndef A3_WAVES
+#define A3_WAVES 4                          // waves per workgroup: 4 (two workgroups per CU, independent phases) or 8
+#endif
+constexpr int A3T = 64 * A3_WAVES;          // threads per workgroup
+constexpr int A3Q = 32 * A3_WAVES;          // queries per workgroup (each wave 32)
+constexpr int A3KI = (1600 + A3T - 1) / A3T;   // K DMA slots per thread (the last one covers only the first wave(s))
+constexpr int A3VI = 1536 / A3T;            // V units per thread
 constexpr int A3K = 64;                     // keys per tile
 // LDS images are padded by one 16-byte unit per row (K: 24 + 1 units, V^T: 8 + 1): an odd row stride in units makes every
 // ds_read_b128 of an MFMA operand conflict-free with plain immediate offsets (no per-lane swizzle arithmetic).
@@ -41,7 +46,7 @@ struct Attn3Args {
 typedef const __attribute__((address_space(1))) void* a3_gptr;
 typedef __attribute__((address_space(3))) void* a3_lptr;
 
-__global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
+__global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(Attn3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                // [2][64 rows][24 units]
     char* Vt = smem + 2 * A3_KS_BYTES;
@@ -73,9 +78,9 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
     //    gp = u >> 6 = 3 kgroup + plane): a wave walks the keys of one (kgroup, plane).
     const char* kbase = a.k + (size_t)b * a.Nk * a.pk + h * 384;
     const char* vbase = a.v + (size_t)b * a.Nk * a.pv + h * 384;
-    int krow_[4], kcu_[4];
+    int krow_[A3KI], kcu_[A3KI];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < A3KI; i++) {
         const int u = min(tid + A3T * i, 1599);
         krow_[i] = u / 25;
         const int cu = u - krow_[i] * 25;
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
     auto issue_k = [&](int k0, int buf) {
         char* base = Ks + buf * A3_KS_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (i == 3 && wave != 0) break;                       // slots 1536..1599: one wave
+        for (int i = 0; i < A3KI; i++) {
+            if (i == A3KI - 1 && wave != 0) break;                // slots 1536..1599: one wave
             const int kk = min(k0 + krow_[i], a.Nk - 1);          // keys past Nk: finite copies, masked to -inf below
             __builtin_amdgcn_global_load_lds((a3_gptr)(kbase + (size_t)kk * a.pk + kcu_[i]), (a3_lptr)(base + A3T * 16 * i), 16, 0, 0);
         }
@@ -94,17 +99,17 @@ __global__ __launch_bounds__(A3T, 1) void attn_bf3_kernel(Attn3Args a) {
     // j = (t & 3) + 4 (t >> 3)   (the order the S^T accumulator holds its keys)
     const int vkey = tid & 63, vt = vkey & 15;
     const int vpos2 = ((vkey & 48) + ((vt >> 2) & 1) * 8 + (vt & 3) + 4 * (vt >> 3)) * 2;
-    u32x4 rv[3];
+    u32x4 rv[A3VI];
     auto load_v = [&](int k0) {
         const int vk = min(k0 + vkey, a.Nk - 1);
         const char* src = vbase + (size_t)vk * a.pv + wave * 16;
 #pragma unroll
-        for (int i = 0; i < 3; i++) rv[i] = *reinterpret_cast<const u32x4*>(src + 128 * i);      // gp = wave + 8 i
+        for (int i = 0; i < A3VI; i++) rv[i] = *reinterpret_cast<const u32x4*>(src + A3_WAVES * 16 * i);      // gp = wave + A3_WAVES i
     };
     auto store_v = [&]() {
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int gp = wave + 8 * i, g = gp / 3, p = gp - 3 * g;                               // wave-uniform
+        for (int i = 0; i < A3VI; i++) {
+            const int gp = wave + A3_WAVES * i, g = gp / 3, p = gp - 3 * g;                        // wave-uniform
             char* dst = Vt + (p * 64 + 8 * g) * A3_VROW + vpos2;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
