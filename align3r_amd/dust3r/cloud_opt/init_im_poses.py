@@ -266,3 +266,57 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
     eng.set_params(pw_poses=pw, depth=depth, im_poses=poses, im_focals=focals)
     if scene.verbose:
         print(' init loss =', float(scene()))
+
+
+# ------------------------------------------------------------------------------------------------ known poses
+def align_multiple_poses(src_poses, target_poses):
+    """(s, R, T) registering camera centres + a point on each optical axis of src onto target (init_im_poses.py:503-511)."""
+    def center_and_z(poses):
+        c = poses[:, :3, 3].double().cpu()
+        n = len(c)
+        d = [float((c[i] - c[j]).norm()) for i in range(n) for j in range(i + 1, n)]
+        eps = float(np.median(d)) / 100 if d else 0.0                 # get_med_dist_between_poses / 100
+        return torch.cat((c, c + eps * poses[:, :3, 2].double().cpu()))
+    x, y = center_and_z(src_poses), center_and_z(target_poses)
+    return rigid_points_registration(x, y, torch.ones(len(x), dtype=torch.float64))
+
+
+def init_from_known_poses(scene, niter_PnP=10, min_conf_thr=3):
+    """init='known_poses' (init_im_poses.py:27-66): every image pose and focal is preset; each pairwise pose is the similarity that
+    carries the pair's two predicted cameras (identity and the PnP pose of view 2) onto the known ones, each depth map the
+    best-confidence pairwise prediction at that scale.  PnP is the linear stand-in above (cv2 absent): parity unpinned."""
+    eng = scene._need_engine()
+    dev = eng.device
+    if eng.flags['train_poses']:
+        raise AssertionError('not all poses are known')
+    if eng.flags['train_focals']:
+        raise AssertionError('not all focals are known')          # the reference asserts nkf == n_imgs
+    H, W = scene.imshape
+    E = len(scene.edges)
+    pred_i, pred_j = eng.pred_i.reshape(E, H, W, 3), eng.pred_j.reshape(E, H, W, 3)
+    conf_i = scene._raw_conf_i.to(dev)
+    known_poses = scene.get_im_poses()
+    im_focals = scene.get_focals().reshape(-1)
+    im_pp = scene.get_principal_points()
+    pw = eng.params['pw_poses'].clone()
+    best = {}
+    for e, (i, j) in enumerate(scene.edges):
+        P1 = torch.eye(4, device=dev)
+        msk = conf_i[e] > min(min_conf_thr, float(conf_i[e].min()) - 0.1)
+        res = linear_pnp(pred_j[e], float(im_focals[i]), msk, pp=(float(im_pp[i, 0]), float(im_pp[i, 1])))
+        if res is None:
+            raise RuntimeError(f'PnP failed on edge ({i},{j})')
+        P2 = res[1]
+        s, R, T = align_multiple_poses(torch.stack((P1, P2)), known_poses[[i, j]])
+        pw[e, 0:4] = rotmat_to_unitquat(R).to(dev)
+        pw[e, 4:7] = signed_log1p(T.to(dev) / s)
+        pw[e, 7] = float(np.log(s))
+        score = float(conf_i[e].mean())
+        if score > best.get(i, (0,))[0]:
+            best[i] = (score, e, s)
+    depth = eng.params['depth'].clone()
+    if not scene.if_use_mono:
+        for n in range(scene.n_imgs):
+            _, e, s = best[n]
+            depth[n] = (pred_i[e][:, :, 2].reshape(-1) * s).log().nan_to_num(neginf=0)
+    eng.set_params(pw_poses=pw, depth=depth)

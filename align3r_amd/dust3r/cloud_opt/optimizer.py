@@ -330,7 +330,8 @@ class PointCloudOptimizer:
             from .init_im_poses import init_minimum_spanning_tree       # parity unpinned (see that module)
             init_minimum_spanning_tree(self, init_priors=init_priors, niter_PnP=niter_PnP)
         elif init == 'known_poses':
-            raise NotImplementedError("init='known_poses' (init_from_known_poses, init_im_poses.py:27-66) is not built")
+            from .init_im_poses import init_from_known_poses              # parity unpinned (see that module)
+            init_from_known_poses(self, niter_PnP=niter_PnP, min_conf_thr=self.min_conf_thr)
         else:
             raise ValueError(f'bad value for {init=}')
         if schedule not in ('cosine', 'linear'):

@@ -210,3 +210,34 @@ def test_encoder_cache_is_bit_identical(model):
     for side, key in (("pred1", "pts3d"), ("pred1", "conf"), ("pred2", "pts3d_in_other_view"), ("pred2", "conf")):
         assert torch.equal(a[side][key], b[side][key]), (side, key)
     assert a["view1"]["idx"] == b["view1"]["idx"]
+
+
+def test_known_poses_initialisation(model):
+    """init='known_poses' (init_im_poses.py:27-66; parity unpinned): with the true poses and focal preset, the initial state
+    must already explain a consistent scene (small loss, depth maps at the scene's scale)."""
+    from dust3r.cloud_opt import global_aligner
+    N, H, W = 4, 32, 48
+    edges, p1, p2, c, cams, depths, f = _geom_scene(N, H, W)
+    out = dict(view1=dict(idx=[i for i, j in edges]), view2=dict(idx=[j for i, j in edges]),
+               pred1=dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c)),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c)))
+    torch.manual_seed(0)
+    scene = global_aligner(out, False, [], "cuda", verbose=False, min_conf_thr=1.5)
+    loss_random = float(scene())
+    with pytest.raises(AssertionError, match="not all poses are known"):
+        scene.compute_global_alignment(init="known_poses", niter=0)
+    poses = []
+    for R, t in cams:
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, t
+        poses.append(torch.from_numpy(T))
+    scene.preset_pose(poses)
+    scene.preset_focal([f] * N)
+    scene.compute_global_alignment(init="known_poses", niter=0)
+    loss_init = float(scene())
+    assert loss_init < 0.02 * loss_random, (loss_init, loss_random)
+    got = torch.stack(scene.get_depthmaps()).cpu().numpy()
+    assert np.abs(got / np.stack(depths) - 1).max() < 0.02            # metric depth at the known poses' scale
+    final = scene.compute_global_alignment(init=None, niter=30, schedule="cosine", lr=0.01)
+    assert final <= loss_init * 1.05
+    assert torch.allclose(scene.get_im_poses().cpu(), torch.stack(poses), atol=1e-5)      # frozen
