@@ -87,7 +87,7 @@ def test_alignment_api_vs_oracle_chain(model, use_mono):
     assert rel_err(scene.get_pw_poses()[:, :3].cpu().numpy(), eM) < 1e-4
     assert scene.get_pts3d()[0].shape == (H, W, 3) and scene.get_intrinsics().shape == (n, 3, 3)
     assert len(scene.get_masks()) == n and scene.get_conf()[0].shape == (H, W)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match="not all poses are known"):       # init_im_poses.py:32
         scene.compute_global_alignment(init="known_poses", niter=1)
 
 
