@@ -14,6 +14,9 @@ def global_aligner(dust3r_output, if_use_mono, mono_depths, device, mode=GlobalA
     view1, view2, pred1, pred2 = [dust3r_output[k] for k in 'view1 view2 pred1 pred2'.split()]
     if mode == GlobalAlignerMode.PointCloudOptimizer:
         return PointCloudOptimizer(view1, view2, pred1, pred2, if_use_mono, mono_depths, **optim_kw).to(device)
-    if mode in (GlobalAlignerMode.ModularPointCloudOptimizer, GlobalAlignerMode.PairViewer):
+    if mode == GlobalAlignerMode.PairViewer:
+        from .pair_viewer import PairViewer
+        return PairViewer(view1, view2, pred1, pred2, if_use_mono, mono_depths, **optim_kw).to(device)
+    if mode == GlobalAlignerMode.ModularPointCloudOptimizer:
         raise NotImplementedError(f'{mode}: only the stacked PointCloudOptimizer fast path is on the hot path (SURVEY.md 8a-12)')
     raise NotImplementedError(f'Unknown mode {mode}')

@@ -96,7 +96,7 @@ def hierarchical_alignment(imgs, model, device, *, clip_size=50, niter=300, sche
     from ..dust3r.inference import inference
 
     if len(imgs) < 3:
-        raise ValueError('hierarchical_alignment needs at least 3 frames (the reference falls back to PairViewer, which is not built)')
+        raise ValueError('hierarchical_alignment needs at least 3 frames (for two frames use GlobalAlignerMode.PairViewer directly)')
     clip_size = choose_clip_size(len(imgs), clip_size)
     coarse_init_pairs, keyframes_id, all_clips_pairs, _ = my_make_pairs(imgs, clip_size)
 

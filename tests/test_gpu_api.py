@@ -241,3 +241,35 @@ def test_known_poses_initialisation(model):
     final = scene.compute_global_alignment(init=None, niter=30, schedule="cosine", lr=0.01)
     assert final <= loss_init * 1.05
     assert torch.allclose(scene.get_im_poses().cpu(), torch.stack(poses), atol=1e-5)      # frozen
+
+
+def test_pair_viewer_two_frames(model):
+    """GlobalAlignerMode.PairViewer (pair_viewer.py; what the drivers use for 2-frame inputs): closed form, parity unpinned
+    (PnP stand-in) -- a consistent two-view scene must give back the focal, the relative pose and both depth maps."""
+    from dust3r.cloud_opt import global_aligner, GlobalAlignerMode
+    N, H, W = 2, 32, 48
+    edges, p1, p2, c, cams, depths, f = _geom_scene(N, H, W)
+    assert edges == [(0, 1), (1, 0)]
+    c[0] *= 1.5                                                    # edge (0,1) is the confident one: world frame = camera 0
+    out = dict(view1=dict(idx=[0, 1]), view2=dict(idx=[1, 0]),
+               pred1=dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c)),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c)))
+    scene = global_aligner(out, False, [], "cuda", mode=GlobalAlignerMode.PairViewer, verbose=False, min_conf_thr=1.5)
+    assert np.isnan(scene.compute_global_alignment(init="mst", niter=10))
+    focals = scene.get_focals().cpu().numpy()
+    assert np.all(np.abs(focals / f - 1) < 0.02)
+    poses = scene.get_im_poses().cpu().numpy().astype(np.float64)
+    assert np.allclose(poses[0], np.eye(4))
+    T0, T1 = np.eye(4), np.eye(4)
+    T0[:3, :3], T0[:3, 3] = cams[0]
+    T1[:3, :3], T1[:3, 3] = cams[1]
+    gt = np.linalg.inv(T0) @ T1
+    assert np.abs(poses[1][:3, :3] - gt[:3, :3]).max() < 0.02
+    assert np.abs(poses[1][:3, 3] / 0.7 - gt[:3, 3]).max() < 0.03           # the scene generator scales pointmaps by 0.7
+    d = [x.cpu().numpy() for x in scene.get_depthmaps()]
+    assert np.abs(d[0] / (0.7 * depths[0]) - 1).max() < 0.01 and np.abs(d[1] / (0.7 * depths[1]) - 1).max() < 0.03
+    assert scene.get_intrinsics().shape == (2, 3, 3) and scene.get_pts3d()[1].shape == (H, W, 3)
+    with pytest.raises(AssertionError):
+        global_aligner(dict(view1=dict(idx=[0]), view2=dict(idx=[1]), pred1=dict(pts3d=torch.from_numpy(p1[:1]), conf=torch.from_numpy(c[:1])),
+                            pred2=dict(pts3d_in_other_view=torch.from_numpy(p2[:1]), conf=torch.from_numpy(c[:1]))),
+                       False, [], "cuda", mode=GlobalAlignerMode.PairViewer, verbose=False)
