@@ -46,6 +46,7 @@ struct Attn3Args {
 typedef const __attribute__((address_space(1))) void* a3_gptr;
 typedef __attribute__((address_space(3))) void* a3_lptr;
 
+template <int NP>
 __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(Attn3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                // [2][64 rows][24 units]
@@ -155,11 +156,15 @@ __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(At
 #pragma unroll
                 for (int p = 0; p < 3; p++)
                     kf[p] = *reinterpret_cast<const bf16x8*>(Kt + kfrag + kb * 32 * A3_KROW + st * 96 + p * 16);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[st][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][1], s, 0, 0, 0);
+                if (NP == 6) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[st][0], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][1], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][2], s, 0, 0, 0);
+                }
+                if (NP >= 3) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[st][0], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][1], s, 0, 0, 0);
+                }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[st][0], s, 0, 0, 0);
             }
             // ---- online softmax (keys of this lane: k0 + 32 kb + (e&3) + 8*(e>>2) + 4*half)
@@ -209,11 +214,15 @@ __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(At
 #pragma unroll
                     for (int p = 0; p < 3; p++)
                         vf[p] = *reinterpret_cast<const bf16x8*>(Vt + vfrag + (p * 64 + db * 32) * A3_VROW + (kb * 4 + s2 * 2) * 16);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], b0, oacc[db], 0, 0, 0);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b1, oacc[db], 0, 0, 0);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b2, oacc[db], 0, 0, 0);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b0, oacc[db], 0, 0, 0);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b1, oacc[db], 0, 0, 0);
+                    if (NP == 6) {
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2], b0, oacc[db], 0, 0, 0);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b1, oacc[db], 0, 0, 0);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b2, oacc[db], 0, 0, 0);
+                    }
+                    if (NP >= 3) {
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], b0, oacc[db], 0, 0, 0);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b1, oacc[db], 0, 0, 0);
+                    }
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], b0, oacc[db], 0, 0, 0);
                 }
             }
@@ -252,8 +261,9 @@ extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ld
                     reinterpret_cast<uintptr_t>(o3)) & 15) == 0, "a3r_attention_bf3: pointers must be 16-byte aligned");
     static bool attr_done = false;
     if (!attr_done) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    A3_LDS_BYTES));
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
         attr_done = true;
     }
     Attn3Args a = {static_cast<const char*>(q3), static_cast<const char*>(k3), static_cast<const char*>(v3), static_cast<char*>(o3),
@@ -261,7 +271,10 @@ extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ld
     const int nqb = (Nq + A3Q - 1) / A3Q, groups = B * H;
     dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION_BF3, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
-    hipLaunchKernelGGL(attn_bf3_kernel, grid, dim3(A3T), A3_LDS_BYTES, as_stream(stream), a);
+    const int np = bf3_products();       // process-wide arithmetic mode (a3r_bf3_set_products)
+    if (np == 6) hipLaunchKernelGGL(attn_bf3_kernel<6>, grid, dim3(A3T), A3_LDS_BYTES, as_stream(stream), a);
+    else if (np == 3) hipLaunchKernelGGL(attn_bf3_kernel<3>, grid, dim3(A3T), A3_LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL(attn_bf3_kernel<1>, grid, dim3(A3T), A3_LDS_BYTES, as_stream(stream), a);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }

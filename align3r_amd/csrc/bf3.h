@@ -9,6 +9,8 @@
 
 namespace a3r {
 
+int bf3_products();        // 6 | 3 | 1: the process-wide product set of the bf3 kernels (gemm_bf3.hip)
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

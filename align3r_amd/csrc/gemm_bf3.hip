@@ -47,7 +47,9 @@ __device__ __attribute__((aligned(16))) unsigned int g_bf3_zero[4];
 // AMODE 0: A is a bf3 matrix [M, K].  AMODE 1: implicit 3x3 conv (padding 1, stride 1 or 2) over a bf3 channels-last map
 // x [B, H, W, Cin]: row m of A is output pixel m, its K axis is (tap, ci) -- stage kt covers BK channels of ONE tap, i.e.
 // 6 BK contiguous bytes of one input pixel, or zeros where the tap falls into the padding.
-template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
+// NP: plane products evaluated -- 6: fp32-accurate (default); 3: a0b0 + a0b1 + a1b0 (operands effectively 16 bits, error
+// ~2^-17 per product); 1: a0b0 only = plain bf16 operands with fp32 accumulation (BASELINE config 5's "bf16-MFMA mode").
+template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL, int NP>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     constexpr bool M16 = MF == 16;
     static_assert(MF == 32 || (MF == 16 && BK == 32), "16x16x32 MFMA needs BK = 32");
@@ -188,11 +190,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
                         // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        if (NP == 6) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        }
+                        if (NP >= 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                     }
             }
@@ -232,11 +238,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    if (NP == 6) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    }
+                    if (NP >= 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
         }
@@ -277,9 +287,13 @@ static int choose_bf3_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL>
+// process-wide arithmetic mode of the bf3 kernels (a3r_bf3_set_products): 6 (fp32-accurate), 3 or 1
+static int g_bf3_products = 6;
+int bf3_products() { return g_bf3_products; }
+
+template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, bool FULL, int NP>
 static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
-    auto kern = gemm_bf3_kernel<AMODE, BM, BN, BK, WM, WN, NS, MF, FULL>;
+    auto kern = gemm_bf3_kernel<AMODE, BM, BN, BK, WM, WN, NS, MF, FULL, NP>;
     constexpr int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
@@ -301,13 +315,29 @@ static int launch_bf3(GemmArgs& g, hipStream_t st) {
     g.tiles_per_group = g.tiles_m * g.tiles_n;
     const bool full = g.M % bm == 0 && g.N % bn == 0;
     ProfScope prof(AMODE == 0 ? PK_LINEAR_BF3 : PK_CONV_BF3, 2.0 * g.M * g.N * g.K * g.groups, st);
-    if (t == 0) return full ? launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, true>(g, st) : launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, false>(g, st);
-    if (t == 1) return full ? launch_bf3_variant<AMODE, 128, 64, 32, 2, 2, 2, 16, true>(g, st) : launch_bf3_variant<AMODE, 128, 64, 32, 2, 2, 2, 16, false>(g, st);
-    return full ? launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, true>(g, st) : launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, false>(g, st);
+#define A3R_BF3_DISPATCH(NPV)                                                                                                   \
+    do {                                                                                                                        \
+        if (t == 0) return full ? launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, true, NPV>(g, st)                        \
+                                : launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, false, NPV>(g, st);                      \
+        if (t == 1) return full ? launch_bf3_variant<AMODE, 128, 64, 32, 2, 2, 2, 16, true, NPV>(g, st)                         \
+                                : launch_bf3_variant<AMODE, 128, 64, 32, 2, 2, 2, 16, false, NPV>(g, st);                       \
+        return full ? launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, true, NPV>(g, st)                                      \
+                    : launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, false, NPV>(g, st);                                    \
+    } while (0)
+    if (g_bf3_products == 6) A3R_BF3_DISPATCH(6);
+    if (g_bf3_products == 3) A3R_BF3_DISPATCH(3);
+    A3R_BF3_DISPATCH(1);
+#undef A3R_BF3_DISPATCH
 }
 
 }  // namespace a3r
 using namespace a3r;
+
+extern "C" int a3r_bf3_set_products(int products) {
+    const int prev = g_bf3_products;
+    if (products == 6 || products == 3 || products == 1) g_bf3_products = products;
+    return prev;
+}
 
 extern "C" size_t a3r_bf3_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)rows * K * 6 : 0; }
 

@@ -62,6 +62,7 @@ struct a3r_model_s {
     std::map<std::string, std::pair<const float*, size_t>> taps;
     // nn.Linear weights also kept in bf3 form (gemm_bf3.hip) unless A3R_GEMM=f32: fp32 pointer -> bf3 twin in `packed`
     bool use_bf3 = true;
+    int products = 6;         // bf3 plane products per multiply: 6 = fp32-accurate; A3R_GEMM=bf3x3 -> 3, A3R_GEMM=bf16 -> 1 (reduced precision)
     std::map<const float*, const void*> w3;
     static constexpr int MAX_POS = 256;
 };
@@ -81,7 +82,11 @@ extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
     a3r_model_s* m = new (std::nothrow) a3r_model_s();
     A3R_CHECK_ARG(m, "out of host memory");
     m->cfg = *cfg;
-    if (const char* e = getenv("A3R_GEMM")) m->use_bf3 = std::string(e) != "f32";
+    if (const char* e = getenv("A3R_GEMM")) {
+        const std::string mode(e);
+        m->use_bf3 = mode != "f32";
+        m->products = mode == "bf16" ? 1 : mode == "bf3x3" ? 3 : 6;
+    }
     // sized here so that the host-side sizing pass (a3r_model_workspace_bytes) works before finalize
     m->enc.assign(cfg->enc_depth, BlockW());
     m->pc.assign(n_pc_blocks(*cfg), BlockW());
@@ -598,6 +603,11 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     const a3r_model_config& c = m->cfg;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, F = c.feature_dim, L = c.last_dim;
     const int nh = H / 16, nw = W / 16, N = nh * nw, BN = B * N, M2 = 2 * BN;
+    struct ProductsGuard {      // the handle's arithmetic mode for the duration of this plan
+        int prev; bool on;
+        ProductsGuard(bool on_, int p) : prev(6), on(on_) { if (on) prev = a3r_bf3_set_products(p); }
+        ~ProductsGuard() { if (on) a3r_bf3_set_products(prev); }
+    } products_guard(!dry && m->use_bf3, m->products);
     Plan P;
     P.m = m; P.stream = stream;
     P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};

@@ -116,6 +116,11 @@ def linear_grouped(xs, ws, biases, epi=_lib.EPI_NONE, resids=None, **kw):
     return outs
 
 
+def bf3_set_products(n: int) -> int:
+    """Arithmetic mode of the bf3 kernels: 6 (fp32-accurate, default), 3 or 1 (plain bf16 operands).  Returns the previous mode."""
+    return int(_lib.load().a3r_bf3_set_products(int(n)))
+
+
 class Bf3:
     """An fp32 matrix [rows, K] in bf3 form (three exact bf16 planes, include/a3r.h): uint8 storage + logical shape."""
 

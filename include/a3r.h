@@ -128,6 +128,11 @@ int a3r_linear_grouped(const a3r_group_ptrs* groups, int n_groups, int lda, int 
  * <= 2^-23 |x w| per product), so y matches a3r_linear to fp32 rounding while running on the 16x faster bf16 MFMA
  * pipes.  Replaces the same call sites as a3r_linear (blocks.py:58-169); epilogues as above. K % 32 == 0. */
 size_t a3r_bf3_bytes(long rows, int K);
+/* Process-wide arithmetic mode of the bf3 kernels (a3r_linear_bf3 / a3r_conv3x3_bf3 / a3r_attention_bf3): the plane products
+ * evaluated per multiply.  6 (default): all products down to 2^-16, fp32-accurate.  3: a0 b0 + a0 b1 + a1 b0, operands
+ * effectively 16 bits (error ~2^-17 per product).  1: a0 b0 only = plain bf16 operands, fp32 accumulation -- BASELINE config 5's
+ * "bf16-MFMA mode", a reduced-precision mode that is never the default.  Returns the previous value; other values are ignored. */
+int a3r_bf3_set_products(int products);
 /* fp32 x [M, ldx] (first K columns) -> bf3 y [M][K/8][3][8] */
 int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream);
 /* nn.LayerNorm (as a3r_layernorm) writing its output directly in bf3 form (D % 8 == 0): the producer of every

@@ -169,3 +169,34 @@ def test_attention_bf3(ops, B, H, Nq, Nk):
     # the output is a valid bf3 matrix of the fp32-rounded result: planes are non-overlapping
     p = o3.planes()
     assert float((p[1].abs() > p[0].abs() * 2.0 ** -7 + 1e-38).sum()) == 0
+
+
+def test_reduced_product_modes(ops):
+    """a3r_bf3_set_products: 3 products = 16-bit operands, 1 product = plain bf16 operands (BASELINE config 5's mode).  Error against
+    float64 relative to sum|x||w|: 6 -> fp32 level, 3 -> ~1e-6, 1 -> bf16 level; the mode is restored afterwards."""
+    M, N, K = 512, 384, 1024
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    x3, w3 = ops.split_bf3(x), ops.split_bf3(w)
+    ref = x.double() @ w.double().T
+    mag = x.double().abs() @ w.double().abs().T
+    err = {}
+    try:
+        for n in (6, 3, 1):
+            assert ops.bf3_set_products(n) in (6, 3, 1)
+            err[n] = float(((ops.linear_bf3(x3, w3).double() - ref).abs() / mag).max())
+    finally:
+        ops.bf3_set_products(6)
+    assert err[6] < 4e-7 and err[6] < err[3] < 4e-6 and 1e-5 < err[1] < 2e-3, err
+    assert ops.bf3_set_products(7) == 6 and ops.bf3_set_products(6) == 6        # invalid values are ignored
+    # attention in bf16 mode stays within bf16 tolerance of the exact result
+    B, H, Nq = 1, 2, 256
+    q, k, v = rnd(B * Nq, H * 64, seed=4), rnd(B * Nq, H * 64, seed=5), rnd(B * Nq, H * 64, seed=6)
+    args = (ops.split_bf3(q), ops.split_bf3(k), ops.split_bf3(v), B, H, Nq, Nq)
+    exact = ops.attention_bf3(*args).planes().sum(0)
+    try:
+        ops.bf3_set_products(1)
+        low = ops.attention_bf3(*args).planes().sum(0)
+    finally:
+        ops.bf3_set_products(6)
+    e = rel_err(cpu(low), cpu(exact))
+    assert 1e-5 < e < 3e-2, e

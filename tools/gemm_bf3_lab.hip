@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restr
             const int rem = nk - 1 - kt;
             wait_stages(rem < NS - 2 ? rem : NS - 2);
             __builtin_amdgcn_s_barrier();
-            if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+            if (!(VAR & 4) && kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
             const char* sb = smem + (kt % NS) * STAGE;
             bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
@@ -192,12 +192,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restr
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    if (!(VAR & 24)) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    }
+                    if (!(VAR & 16)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    else {      // no MFMA at all: keep the fragment reads alive with one VALU op per fragment
+#pragma unroll
+                        for (int p = 0; p < 3; p++) acc[i][j][0] += (float)af[i][p][0] + (float)bf[j][p][0];
+                    }
                 }
             if (VAR & 1) __builtin_amdgcn_s_setprio(0);
         }
@@ -292,17 +298,14 @@ int main(int argc, char** argv) {
         };
         int bit = 0;
 #define RUN(name, ...) do { if (mask & (1u << bit)) { run<__VA_ARGS__>(name, Ap, Wp, C, M, N, K, it); check(name); } bit++; } while (0)
-        RUN("256x128x32 8w NS2 m16", 256, 128, 32, 4, 2, 2, 2);
-        RUN("256x128x32 8w NS2 m16 prio", 256, 128, 32, 4, 2, 2, 3);
-        RUN("256x128x32 8w(2x4) NS2 m16", 256, 128, 32, 2, 4, 2, 2);
-        RUN("128x256x32 8w(2x4) NS2 m16", 128, 256, 32, 2, 4, 2, 2);
-        RUN("128x128x32 8w(4x2) NS2 m16", 128, 128, 32, 4, 2, 2, 2);
-        RUN("128x128x32 8w(4x2) NS3 m16", 128, 128, 32, 4, 2, 3, 2);
-        RUN("128x128x32 8w(2x4) NS3 m16", 128, 128, 32, 2, 4, 3, 2);
-        RUN("256x128x32 16w(4x4) NS2 m16", 256, 128, 32, 4, 4, 2, 2);
-        RUN("128x64x32 4w NS2 m16", 128, 64, 32, 2, 2, 2, 2);
-        RUN("128x64x32 4w NS3 m16 prio", 128, 64, 32, 2, 2, 3, 3);
-        RUN("64x64x32 4w NS3 m16", 64, 64, 32, 2, 2, 3, 2);
+        RUN("256x128 16w m16 full", 256, 128, 32, 4, 4, 2, 2);
+        RUN("256x128 16w m16 1 product", 256, 128, 32, 4, 4, 2, 2 | 8);
+        RUN("256x128 16w m16 0 products", 256, 128, 32, 4, 4, 2, 2 | 16);
+        RUN("256x128 16w m16 full, no DMA", 256, 128, 32, 4, 4, 2, 2 | 4);
+        RUN("256x128 16w m16 0 products, no DMA", 256, 128, 32, 4, 4, 2, 2 | 4 | 16);
+        RUN("128x64 4w m16 full", 128, 64, 32, 2, 2, 2, 2);
+        RUN("128x64 4w m16 0 products", 128, 64, 32, 2, 2, 2, 2 | 16);
+        RUN("128x64 4w m16 full, no DMA", 128, 64, 32, 2, 2, 2, 2 | 4);
         CK(hipFree(Ap)); CK(hipFree(Wp)); CK(hipFree(C));
     }
     return 0;
