@@ -298,14 +298,14 @@ int main(int argc, char** argv) {
         };
         int bit = 0;
 #define RUN(name, ...) do { if (mask & (1u << bit)) { run<__VA_ARGS__>(name, Ap, Wp, C, M, N, K, it); check(name); } bit++; } while (0)
-        RUN("256x128 16w m16 full", 256, 128, 32, 4, 4, 2, 2);
-        RUN("256x128 16w m16 1 product", 256, 128, 32, 4, 4, 2, 2 | 8);
-        RUN("256x128 16w m16 0 products", 256, 128, 32, 4, 4, 2, 2 | 16);
-        RUN("256x128 16w m16 full, no DMA", 256, 128, 32, 4, 4, 2, 2 | 4);
-        RUN("256x128 16w m16 0 products, no DMA", 256, 128, 32, 4, 4, 2, 2 | 4 | 16);
-        RUN("128x64 4w m16 full", 128, 64, 32, 2, 2, 2, 2);
-        RUN("128x64 4w m16 0 products", 128, 64, 32, 2, 2, 2, 2 | 16);
-        RUN("128x64 4w m16 full, no DMA", 128, 64, 32, 2, 2, 2, 2 | 4);
+        RUN("128x128 8w m16 NS2 0prod", 128, 128, 32, 4, 2, 2, 2 | 16);
+        RUN("128x128 8w m16 NS3 0prod", 128, 128, 32, 4, 2, 3, 2 | 16);
+        RUN("128x128 8w m16 NS2 full", 128, 128, 32, 4, 2, 2, 2);
+        RUN("128x128 8w m16 NS3 full", 128, 128, 32, 4, 2, 3, 2);
+        RUN("128x64 4w m16 NS2 0prod", 128, 64, 32, 2, 2, 2, 2 | 16);
+        RUN("128x64 4w m16 NS4 0prod", 128, 64, 32, 2, 2, 4, 2 | 16);
+        RUN("128x64 4w m16 NS4 full", 128, 64, 32, 2, 2, 4, 2);
+        RUN("256x128 16w m16 NS2 0prod", 256, 128, 32, 4, 4, 2, 2 | 16);
         CK(hipFree(Ap)); CK(hipFree(Wp)); CK(hipFree(C));
     }
     return 0;
