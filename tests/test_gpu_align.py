@@ -57,6 +57,21 @@ def test_adam_trajectory_vs_reference(case, g, Engine):
             ref = g[f"{tag}_k{k}_{names[kk]}"]
             assert rel_err(host(a.params[kk]).reshape(ref.shape), ref) < 1e-4, (k, kk)
     assert rel_err(np.asarray(losses), g[tag + "_losses"]) < 1e-5
+    # north star: aligned-depth AbsRel within 1e-4 of the reference (tool/depth_test.py:689-812).  No Sintel data offline, so
+    # the "ground truth" is synthetic (the reference's own aligned depth, smoothly perturbed): what is pinned is that the HIP
+    # aligner's depth maps and the reference's give the same metric under the reference's evaluation rule (LAD scale + shift).
+    from align3r_amd.tool.depth_metrics import evaluate_depth
+    if not case["use_mono"]:
+        d_ref = np.exp(g[f"{tag}_k50_{names['depth']}"].astype(np.float64))
+        d_hip = np.exp(host(a.params["depth"]).astype(np.float64)).reshape(d_ref.shape)
+        n = d_ref.shape[0]
+        yy = np.linspace(0, 1, d_ref[0].size).reshape(1, -1)
+        gt = (2.0 * d_ref.reshape(n, -1) + 0.1) * (1 + 0.2 * np.sin(7 * yy + np.arange(n)[:, None]))
+        m_ref = evaluate_depth(d_ref.reshape(n, 1, -1), gt.reshape(n, 1, -1), depth_max=1e9, mode="lad")
+        m_hip = evaluate_depth(d_hip.reshape(n, 1, -1), gt.reshape(n, 1, -1), depth_max=1e9, mode="lad")
+        assert m_ref["abs_rel"] > 0.01                         # a non-trivial metric value
+        assert abs(m_hip["abs_rel"] - m_ref["abs_rel"]) < 1e-4, (m_hip, m_ref)
+        assert abs(m_hip["d1"] - m_ref["d1"]) < 1e-3
 
 
 def _scene(E_graph, N, H, W, seed, mono):

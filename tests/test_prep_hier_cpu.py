@@ -145,3 +145,24 @@ def test_tum_pose_conversion_and_writers(tmp_path):
     assert rows[0] == "500.000000 0.000000 256.000000 0.000000 500.000000 192.000000 0.000000 0.000000 1.000000" and len(rows) == 4
     hz.save_frame_arrays([np.ones((2, 3), np.float32)] * 2, str(tmp_path), "frame_{:04d}.npy", start=5)
     assert sorted(p.name for p in tmp_path.glob("frame_*.npy")) == ["frame_0005.npy", "frame_0006.npy"]
+
+
+def test_depth_metrics_rules():
+    from align3r_amd.tool.depth_metrics import align_depth, evaluate_depth
+    rng = np.random.RandomState(0)
+    gt = 1 + 9 * rng.rand(3, 16, 20)
+    pred = (gt - 0.3) / 2.5                                   # exact affine relation: lstsq and lad recover it
+    for mode in ("lstsq", "lad"):
+        m = evaluate_depth(pred, gt, depth_max=70, mode=mode)
+        assert m["abs_rel"] < 1e-6 and m["d1"] == 1.0 and m["n_valid"] == gt.size, (mode, m)
+    m = evaluate_depth(gt / 3.0, gt, mode="scale")
+    assert m["abs_rel"] < 1e-6
+    m = evaluate_depth(gt / 3.0, gt, mode="median")
+    assert m["abs_rel"] < 1e-9 and m["rmse"] < 1e-8
+    noisy = pred * (1 + 0.05 * rng.randn(*pred.shape))
+    m = evaluate_depth(noisy, gt, mode="lad")
+    assert 0.01 < m["abs_rel"] < 0.08 and m["d1"] > 0.95
+    gt2 = gt.copy(); gt2[0, :4] = 0.0; gt2[1, :2] = 100.0    # masked out by 1e-3 < gt < depth_max
+    assert evaluate_depth(pred, gt2, depth_max=70, mode="lstsq")["n_valid"] == gt.size - 4 * 20 - 2 * 20
+    with pytest.raises(ValueError):
+        align_depth(pred, gt, mode="nope")

@@ -265,7 +265,7 @@ int main(int argc, char** argv) {
     const unsigned mask = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 0) : 0xffffffffu;
     int shape_idx = -1;
     const int shapes[][3] = {{4096, 4096, 4096}, {18432, 4096, 1024}, {18432, 3072, 1024}, {18432, 1024, 1024}, {18432, 1024, 4096},
-                             {18432, 768, 768}, {18432, 768, 3072}};
+                             {18432, 768, 768}, {18432, 768, 3072}, {64512, 4096, 1024}, {64512, 1024, 1024}, {64512, 768, 768}};
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
         shape_idx++;
@@ -298,14 +298,11 @@ int main(int argc, char** argv) {
         };
         int bit = 0;
 #define RUN(name, ...) do { if (mask & (1u << bit)) { run<__VA_ARGS__>(name, Ap, Wp, C, M, N, K, it); check(name); } bit++; } while (0)
-        RUN("128x128 8w m16 NS2 0prod", 128, 128, 32, 4, 2, 2, 2 | 16);
-        RUN("128x128 8w m16 NS3 0prod", 128, 128, 32, 4, 2, 3, 2 | 16);
-        RUN("128x128 8w m16 NS2 full", 128, 128, 32, 4, 2, 2, 2);
-        RUN("128x128 8w m16 NS3 full", 128, 128, 32, 4, 2, 3, 2);
-        RUN("128x64 4w m16 NS2 0prod", 128, 64, 32, 2, 2, 2, 2 | 16);
-        RUN("128x64 4w m16 NS4 0prod", 128, 64, 32, 2, 2, 4, 2 | 16);
-        RUN("128x64 4w m16 NS4 full", 128, 64, 32, 2, 2, 4, 2);
-        RUN("256x128 16w m16 NS2 0prod", 256, 128, 32, 4, 4, 2, 2 | 16);
+        RUN("256x128 16w m16 NS2", 256, 128, 32, 4, 4, 2, 2);
+        RUN("256x256x16 8w(4x2) m32 NS3", 256, 256, 16, 4, 2, 3, 0);
+        RUN("256x256x16 8w(2x4) m32 NS3", 256, 256, 16, 2, 4, 3, 0);
+        RUN("256x256x16 16w(4x4) m32 NS3", 256, 256, 16, 4, 4, 3, 0);
+        RUN("128x64 4w m16 NS2", 128, 64, 32, 2, 2, 2, 2);
         CK(hipFree(Ap)); CK(hipFree(Wp)); CK(hipFree(C));
     }
     return 0;
