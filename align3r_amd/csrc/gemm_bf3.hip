@@ -254,6 +254,130 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     }
 }
 
+// ---- 256 x 256 tile ("W in two halves"), nn.Linear only.  Operand delivery L2 -> LDS, not the matrix cores, is what bounds
+// the kernel above, so this variant spends the same 144 KB of LDS on a tile with 2/3 of the delivery bytes per
+// flop: A stages are double-buffered (2 x 48 KB), W holds ONE stage as two 128-column halves (2 x 24 KB).  Eight waves, each a
+// 32-row strip over all 256 columns (2 x 16 accumulator tiles): a stage multiplies the strip by half 0, then by half 1; half 0
+// is refilled for the next stage at the mid-stage barrier, half 1 and the next A stage at the stage barrier.
+template <bool FULL, int NP>
+__global__ __launch_bounds__(512) void gemm_bf3_w2h_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, HN = 128, NT = 512, U = 12;
+    constexpr int A_BYTES = BM * U * 16, H_BYTES = HN * U * 16;
+    constexpr int LA = BM * U / NT, LH = HN * U / NT;                      // 6, 3 DMAs per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                        // [2][256 rows][12 units]
+    char* Hs = smem + 2 * A_BYTES;          // [2 halves][128 rows][12 units]
+
+    const int nwg = g.tiles_per_group * g.groups;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int grp = wgid / g.tiles_per_group;
+    wgid -= grp * g.tiles_per_group;
+    const GroupPtrs& P = g.grp[grp];
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid - tile_m * g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t pitch = (size_t)g.K * 6;
+    // 32-bit byte offsets from the tile's first row (256 rows x <= 24 KB); rows past M / N re-read the last valid row
+    unsigned offA[LA], offW[2][LH];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        const int slot = tid + NT * i, r = slot / U, cp = slot % U;
+        const int rr = FULL ? r : min(m0 + r, g.M - 1) - m0;
+        offA[i] = (unsigned)(rr * pitch) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < LH; i++) {
+            const int slot = tid + NT * i, r = slot / U, cp = slot % U;
+            const int rr = FULL ? h * HN + r : min(n0 + h * HN + r, g.N - 1) - n0;
+            offW[h][i] = (unsigned)(rr * pitch) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;
+        }
+    const char* Abase = reinterpret_cast<const char*>(P.A) + (size_t)m0 * pitch;
+    const char* Wbase = reinterpret_cast<const char*>(P.Wt) + (size_t)n0 * pitch;
+    auto issue_a = [&](int kt, int buf) {
+        char* base = As + buf * A_BYTES + wave * 1024;
+        const char* src = Abase + (size_t)kt * 192;
+#pragma unroll
+        for (int i = 0; i < LA; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[i]), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt, int half) {
+        char* base = Hs + half * H_BYTES + wave * 1024;
+        const char* src = Wbase + (size_t)kt * 192;
+#pragma unroll
+        for (int i = 0; i < LH; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + offW[half][i]), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
+    };
+    f32x4 acc[8][2][2];                     // [32-column pair][row tile][column tile of the pair]
+#pragma unroll
+    for (int cpair = 0; cpair < 8; cpair++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[cpair][i][j][e] = 0.f;
+    const int frow = lane & 15, kg = lane >> 4, rotk = 2 * ((frow >> 3) & 1);
+    int fo[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) fo[p] = (frow * U + 3 * ((kg - rotk + 4) % 4) + p) * 16;
+    const int nk = g.K / 32;
+    issue_a(0, 0);
+    issue_w(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        wait_vmcnt<0>();                                // A_kt and W-half-0 of stage kt (this wave's share) have landed
+        __builtin_amdgcn_s_barrier();                   // ... everyone's; and every wave is done with stage kt-1
+        issue_w(kt, 1);                                 // half 1 of THIS stage (its buffer held half 1 of stage kt-1)
+        if (kt + 1 < nk) issue_a(kt + 1, (kt + 1) & 1);
+        const char* sa = As + (kt & 1) * A_BYTES + wave * 32 * U * 16;
+        bf16x8 af[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(sa + fo[p] + i * 16 * U * 16);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (half == 1) {
+                if (kt + 1 < nk) wait_vmcnt<LA>(); else wait_vmcnt<0>();       // half 1 landed; A of stage kt+1 may stay in flight
+                __builtin_amdgcn_s_barrier();                                   // everyone is done with half 0 of this stage
+                if (kt + 1 < nk) issue_w(kt + 1, 0);
+            }
+            const char* sw = Hs + half * H_BYTES;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {               // 4 column tiles at a time (fragment registers)
+                bf16x8 bf[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8*>(sw + fo[p] + (c * 4 + j) * 16 * U * 16);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        f32x4& a = acc[half * 4 + c * 2 + (j >> 1)][i][j & 1];
+                        if (NP == 6) {
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], a, 0, 0, 0);
+                        }
+                        if (NP >= 3) {
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], a, 0, 0, 0);
+                        }
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], a, 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // eight explicit calls (a loop here is not unrolled at this body size, which would send the accumulators to scratch)
+#define A3R_W2H_EPI(CP) gemm_epilogue16<2, 2, FULL>(g, P, acc[CP], m0, n0, wave * 32, (CP) * 32, lane)
+    A3R_W2H_EPI(0); A3R_W2H_EPI(1); A3R_W2H_EPI(2); A3R_W2H_EPI(3); A3R_W2H_EPI(4); A3R_W2H_EPI(5); A3R_W2H_EPI(6); A3R_W2H_EPI(7);
+#undef A3R_W2H_EPI
+}
+
 // fp32 [M, ldx] -> bf3 [M][K/8][3][8]: one thread per group of 8 consecutive k (32 B in, 48 contiguous bytes out)
 __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8) {
     const long total = M * K8;
@@ -269,16 +393,19 @@ struct Bf3Tile { int bm, bn, occ; double eff; };
 // Tile shapes and their main-loop efficiencies measured on MI355X (tools/gemm_bf3_lab.hip, 18432-row ViT-L shapes, all on
 // the 16x16x32 MFMA): 256x128 with 16 waves (4x4, one workgroup per CU) ~205, 128x64 with 4 waves (two workgroups per CU)
 // ~180-210, 64x64 ~150 TFLOP/s fp32-equivalent.  A launch of n workgroups takes ceil(n / (256 occ)) rounds.
-static const Bf3Tile kTiles[3] = {{256, 128, 1, 1.0}, {128, 64, 2, 0.95}, {64, 64, 2, 0.75}};
+// Tile 3 = the 256x256 "W in two halves" kernel (nn.Linear only): 2/3 of tile 0's delivery bytes per flop; measured equal to
+// tile 0 per flop on the ViT-L shapes (its 256 KB-per-workgroup epilogue eats the gain), so it wins only through quantisation.
+static const Bf3Tile kTiles[4] = {{256, 128, 1, 1.0}, {128, 64, 2, 0.95}, {64, 64, 2, 0.75}, {256, 256, 1, 0.99}};
 
-static int choose_bf3_tile(int M, int N, int groups) {
-    if (const char* f = getenv("A3R_BF3_TILE")) {      // developer override: 0 | 1 | 2
+static int choose_bf3_tile(int M, int N, int groups, bool linear) {
+    const int ntiles = linear ? 4 : 3;
+    if (const char* f = getenv("A3R_BF3_TILE")) {      // developer override: 0 | 1 | 2 | 3
         const int t = atoi(f);
-        if (t >= 0 && t < 3) return t;
+        if (t >= 0 && t < ntiles) return t;
     }
     int best_t = 0;
     double best = 1e300;
-    for (int t = 0; t < 3; t++) {
+    for (int t = 0; t < ntiles; t++) {
         const long n = (long)((M + kTiles[t].bm - 1) / kTiles[t].bm) * ((N + kTiles[t].bn - 1) / kTiles[t].bn) * groups;
         const long slots = 256L * kTiles[t].occ;
         const double cost = (double)((n + slots - 1) / slots) * kTiles[t].bm * kTiles[t].bn * kTiles[t].occ / kTiles[t].eff;
@@ -306,9 +433,23 @@ static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
     return A3R_OK;
 }
 
+template <bool FULL, int NP>
+static int launch_bf3_w2h(const GemmArgs& g, hipStream_t st) {
+    auto kern = gemm_bf3_w2h_kernel<FULL, NP>;
+    constexpr int lds = 2 * 256 * 192 + 2 * 128 * 192;
+    static bool attr_done = false;
+    if (!attr_done) {
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(512), lds, st, g);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
 template <int AMODE>
 static int launch_bf3(GemmArgs& g, hipStream_t st) {
-    const int t = choose_bf3_tile(g.M, g.N, g.groups);
+    const int t = choose_bf3_tile(g.M, g.N, g.groups, AMODE == 0);
     const int bm = kTiles[t].bm, bn = kTiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -324,6 +465,11 @@ static int launch_bf3(GemmArgs& g, hipStream_t st) {
         return full ? launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, true, NPV>(g, st)                                      \
                     : launch_bf3_variant<AMODE, 64, 64, 32, 2, 2, 3, 16, false, NPV>(g, st);                                    \
     } while (0)
+    if (AMODE == 0 && t == 3) {
+        const int np = g_bf3_products;
+        if (full) return np == 6 ? launch_bf3_w2h<true, 6>(g, st) : np == 3 ? launch_bf3_w2h<true, 3>(g, st) : launch_bf3_w2h<true, 1>(g, st);
+        return np == 6 ? launch_bf3_w2h<false, 6>(g, st) : np == 3 ? launch_bf3_w2h<false, 3>(g, st) : launch_bf3_w2h<false, 1>(g, st);
+    }
     if (g_bf3_products == 6) A3R_BF3_DISPATCH(6);
     if (g_bf3_products == 3) A3R_BF3_DISPATCH(3);
     A3R_BF3_DISPATCH(1);

@@ -87,16 +87,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const GroupPtrs
 // bf3 outputs (out_bf3: instead of the fp32 store; aux_bf3: in addition to it, optionally through a ReLU): neighbouring
 // lanes (columns c, c+1) trade half of their four rows, so that each lane owns two rows of a column PAIR and stores one
 // packed dword per plane and row (the even lane rows 0-1 of its quad, the odd lane rows 2-3).
-template <int TM, int TN, bool FULL>
-__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
-                                                int wrow0, int wcol0, int lane) {
+// EPI >= 0 / O3 >= 0: the epilogue kind / the presence of a bf3 output fixed at compile time (straight-line code for the hot
+// combinations); -1: decided at run time (generic body).
+template <int TM, int TN, bool FULL, int EPI, int O3>
+__device__ __forceinline__ void gemm_epilogue16_body(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
+                                                     int wrow0, int wcol0, int lane) {
     static_assert(TN % 2 == 0, "pairs of 16-wide tiles");
     const a3r_epilogue& ep = g.epi;
     const int quad = lane >> 4, lcol = lane & 15;
-    const int epi = ep.epi;
+    const int epi = EPI >= 0 ? EPI : ep.epi;
     const bool odd = lane & 1;
-    char* out3 = ep.out_bf3 ? reinterpret_cast<char*>(P.C) : static_cast<char*>(ep.aux_bf3);
-    const bool relu3 = !ep.out_bf3 && ep.aux_relu;
+    const bool only3 = O3 == 0 ? false : ep.out_bf3 != 0;                 // bf3 INSTEAD of the fp32 store
+    char* out3 = O3 == 0 ? nullptr : (only3 ? reinterpret_cast<char*>(P.C) : static_cast<char*>(ep.aux_bf3));
+    const bool relu3 = !only3 && ep.aux_relu;
     const size_t pitch3 = (size_t)g.N * 6;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -129,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
                 else if (epi == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                 else if (epi == A3R_EPI_RESID) { if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + v[e]; }
                 else if (epi == A3R_EPI_RESID2) { if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v[e]; }
-                if (ok && !ep.out_bf3) {
+                if (ok && !only3) {
                     if (epi == A3R_EPI_PIXSHUF) {
                         const int s = ep.ps_s, hw = ep.ps_h * ep.ps_w;
                         const int b = row / hw, rem = row - b * hw;
@@ -170,6 +173,22 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
                 }
             }
         }
+    }
+}
+
+template <int TM, int TN, bool FULL>
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
+                                                int wrow0, int wcol0, int lane) {
+    const a3r_epilogue& ep = g.epi;
+    const bool has3 = ep.out_bf3 || ep.aux_bf3;                            // wave-uniform dispatch, once per call
+    if (!has3) {
+        if (ep.epi == A3R_EPI_RESID) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_RESID, 0>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else if (ep.epi == A3R_EPI_NONE) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_NONE, 0>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else gemm_epilogue16_body<TM, TN, FULL, -1, 0>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+    } else {
+        if (ep.epi == A3R_EPI_ROPE) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_ROPE, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else if (ep.epi == A3R_EPI_GELU) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_GELU, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else gemm_epilogue16_body<TM, TN, FULL, -1, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
     }
 }
 

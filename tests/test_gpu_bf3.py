@@ -53,7 +53,7 @@ def test_layernorm_bf3_equals_layernorm_then_split(ops, M, D):
     assert torch.equal(y3.data, want.data)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1000, 384, 128), (768, 1024, 1024), (130, 64, 32)])
 def test_linear_bf3_every_tile_shape(ops, monkeypatch, tile, M, N, K):
     from align3r_amd import _lib
@@ -72,7 +72,7 @@ def test_linear_bf3_every_tile_shape(ops, monkeypatch, tile, M, N, K):
         assert rel_err(cpu(y), cpu(want)) < TOL
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1001, 384, 128)])
 def test_linear_bf3_output_in_bf3_form(ops, monkeypatch, tile, M, N, K):
     """fc1 + GELU writing the next GEMM's input directly == the fp32 result split afterwards, bit for bit."""

@@ -30,6 +30,9 @@ def timeit(fn, iters=10):
 
 
 def main():
+    scale = float(os.environ.get("A3R_BENCH_MSCALE", "1"))      # 3.5 = the bench's 42 pairs per step
+    global SHAPES
+    SHAPES = [(n, int(M * scale) if M < 100000 else M, N, K, G, c) for n, M, N, K, G, c in SHAPES]
     tiles = sys.argv[1:] or ["auto", "0", "1"]
     tot = {t: 0.0 for t in tiles}
     print(f"{'shape':18s} {'M':>7s} {'N':>5s} {'K':>5s} g " + " ".join(f"{'tile ' + t:>22s}" for t in tiles))
