@@ -188,7 +188,10 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
     } else {
         if (ep.epi == A3R_EPI_ROPE) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_ROPE, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
         else if (ep.epi == A3R_EPI_GELU) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_GELU, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
-        else gemm_epilogue16_body<TM, TN, FULL, -1, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else if (ep.epi == A3R_EPI_RESID) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_RESID, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else if (ep.epi == A3R_EPI_RESID2) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_RESID2, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else if (ep.epi == A3R_EPI_RELU) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_RELU, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
+        else gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_NONE, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);      // (PIXSHUF has no bf3 form)
     }
 }
 
