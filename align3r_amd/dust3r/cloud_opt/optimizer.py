@@ -268,6 +268,15 @@ class PointCloudOptimizer:
     def get_masks(self):
         return [(conf > self.min_conf_thr) for conf in self.im_conf]
 
+    def clean_pointcloud(self, **kw):
+        """base_opt.py:268-278: lower the confidence of points that another, more confident view sees through."""
+        cams = torch.linalg.inv(self.get_im_poses())
+        new_confs = clean_pointcloud([c.to(self.device) for c in self.im_conf], self.get_intrinsics(), cams, self.get_depthmaps(),
+                                     self.get_pts3d(), **kw)
+        for i, c in enumerate(new_confs):
+            self.im_conf[i] = c.to(self.im_conf[i].device)
+        return self
+
     # ------------------------------------------------------------------ presets (optimizer.py:76-113)
     def _msk_indices(self, msk):
         if msk is None:
@@ -345,3 +354,31 @@ class PointCloudOptimizer:
         if self.verbose:
             print(f'Global alignement - {niter} iterations, final lr={lr_min if niter > 1 else lr:g} loss={losses[-1]:g}')
         return float(losses[-1])
+
+
+def clean_pointcloud(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad_conf=0, dbg=()):
+    """base_opt.py:468-503.  Every image's points are projected into every other view; a point that lands (rounded to a pixel)
+    in front of that view's depth map by more than `tol` while being the less confident of the two has its confidence clipped
+    to `bad_conf`.  The confidences are updated in place of the running copy, pair after pair, in the reference's (i, j) order."""
+    assert len(im_confs) == len(cams) == len(K) == len(depthmaps) == len(all_pts3d)
+    assert 0 <= tol < 1
+    res = [c.clone() for c in im_confs]
+    all_pts3d = [p.reshape(*c.shape, 3) for p, c in zip(all_pts3d, im_confs)]
+    depthmaps = [d.reshape(*c.shape) for d, c in zip(depthmaps, im_confs)]
+    for i, pts3d in enumerate(all_pts3d):
+        for j in range(len(all_pts3d)):
+            if i == j:
+                continue
+            proj = pts3d @ cams[j][:3, :3].T + cams[j][:3, 3]                 # world -> camera j
+            proj_depth = proj[:, :, 2]
+            uvw = proj @ K[j].T
+            uv = (uvw[..., :2] / uvw[..., 2:3]).round().long()                # geotrf(K, proj, norm=1, ncol=2)
+            u, v = uv.unbind(-1)
+            H, W = im_confs[j].shape
+            msk_i = (proj_depth > 0) & (0 <= u) & (u < W) & (0 <= v) & (v < H)
+            msk_j = v[msk_i], u[msk_i]
+            bad_points = (proj_depth[msk_i] < (1 - tol) * depthmaps[j][msk_j]) & (res[i][msk_i] < res[j][msk_j])
+            bad_msk_i = msk_i.clone()
+            bad_msk_i[msk_i] = bad_points
+            res[i][bad_msk_i] = res[i][bad_msk_i].clip(max=bad_conf)
+    return res

@@ -601,7 +601,27 @@ def gen_hier(out):
         P = np.eye(4); P[:3, :3] = R; P[:3, 3] = rng.randn(3)
         poses.append(P.astype(np.float32).tolist())
         tum.append(c2w_to_tumpose(torch.tensor(P, dtype=torch.float32)).tolist())
-    json.dump(dict(make_pairs=cases, clip_rule=rule, poses=poses, tum=tum), open(os.path.join(out, "hier.json"), "w"))
+    # clean_pointcloud (cloud_opt/base_opt.py:468-503) on a small synthetic scene: 3 views of a wavy surface + an occluder
+    from dust3r.cloud_opt.base_opt import clean_pointcloud
+    rs = np.random.RandomState(11)
+    Hc, Wc, nv = 12, 16, 3
+    f = 20.0
+    Kc = torch.tensor([[f, 0, Wc / 2], [0, f, Hc / 2], [0, 0, 1]], dtype=torch.float32).repeat(nv, 1, 1)
+    xs, ys = np.meshgrid(np.arange(Wc), np.arange(Hc))
+    c2w, depth, pts, conf = [], [], [], []
+    for n in range(nv):
+        a = 0.15 * (n - 1)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [0.4 * (n - 1), 0.0, 0.0]
+        d = 3 + 0.5 * np.sin(xs / 3.0 + n) + (rs.rand(Hc, Wc) < 0.15) * (-1.5)       # some points float in front of the surface
+        cam = np.stack([(xs - Wc / 2) * d / f, (ys - Hc / 2) * d / f, d], -1)
+        c2w.append(T); depth.append(d); pts.append(cam @ R.T + T[:3, 3]); conf.append(1 + 5 * rs.rand(Hc, Wc))
+    t32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    cams = torch.linalg.inv(t32(c2w))
+    out_conf = clean_pointcloud([t32(c) for c in conf], Kc, cams, [t32(d) for d in depth], [t32(p) for p in pts], tol=0.001)
+    clean = dict(K=Kc.tolist(), c2w=np.asarray(c2w).tolist(), depth=np.asarray(depth).tolist(), pts=np.asarray(pts).tolist(),
+                 conf=np.asarray(conf).tolist(), out=[c.tolist() for c in out_conf])
+    json.dump(dict(make_pairs=cases, clip_rule=rule, poses=poses, tum=tum, clean=clean), open(os.path.join(out, "hier.json"), "w"))
     print("hier:", len(cases), "pair cases,", len(rule), "clip-size cases")
 
 

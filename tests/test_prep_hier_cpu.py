@@ -166,3 +166,19 @@ def test_depth_metrics_rules():
     assert evaluate_depth(pred, gt2, depth_max=70, mode="lstsq")["n_valid"] == gt.size - 4 * 20 - 2 * 20
     with pytest.raises(ValueError):
         align_depth(pred, gt, mode="nope")
+
+
+def test_clean_pointcloud_matches_reference():
+    """cloud_opt/base_opt.py:468-503 (pure tensor code: runs on the CPU here, on the device inside scene.clean_pointcloud())."""
+    from align3r_amd.dust3r.cloud_opt.optimizer import clean_pointcloud
+    c = json.load(open(os.path.join(GOLDEN, "hier.json")))["clean"]
+    t32 = lambda a: torch.tensor(a, dtype=torch.float32)
+    cams = torch.linalg.inv(t32(c["c2w"]))
+    conf = [t32(x) for x in c["conf"]]
+    out = clean_pointcloud(conf, t32(c["K"]), cams, [t32(d) for d in c["depth"]], [t32(p) for p in c["pts"]], tol=0.001)
+    want = [t32(x) for x in c["out"]]
+    changed = sum(int((a != b).sum()) for a, b in zip(conf, want))
+    assert changed > 5                                         # the fixture exercises the rule
+    for a, b in zip(out, want):
+        assert torch.equal(a, b)
+    assert all(torch.equal(a, t32(b)) for a, b in zip(conf, c["conf"]))   # inputs untouched
