@@ -7,7 +7,7 @@ __version__ = "0.1.0"
 _MIRRORED = ["dust3r", "dust3r.model", "dust3r.inference", "dust3r.image_pairs", "dust3r.cloud_opt",
              "dust3r.cloud_opt.optimizer", "dust3r.cloud_opt.commons", "dust3r.cloud_opt_flow",
              "dust3r.cloud_opt_flow.optimizer", "dust3r.utils", "dust3r.utils.device", "dust3r.utils.image_pose",
-             "dust3r.cloud_opt.pair_viewer", "dust3r.cloud_opt.init_im_poses"]
+             "dust3r.utils.goem_opt", "dust3r.cloud_opt.pair_viewer", "dust3r.cloud_opt.init_im_poses"]
 
 
 def install_as_dust3r():

@@ -56,13 +56,52 @@ class PointCloudOptimizer(_Base):
                 raise NotImplementedError('flow_loss_weight > 0 needs precomputed optical flow: pass flow=(flow_ij, flow_ji) '
                                           '[E,2,H,W]; running RAFT inside the aligner is SURVEY row N4 (not built)')
             if use_self_mask:
-                raise NotImplementedError('use_self_mask (get_motion_mask_from_pairs) is SURVEY row N4 (not built)')
+                self.motion_mask_thre = motion_mask_thre
+                self.get_motion_mask_from_pairs(view1, view2, pred1, pred2, torch.as_tensor(flow[0]).float(), torch.as_tensor(flow[1]).float())
             if self.dynamic_masks is None:
                 raise RuntimeError("flow loss needs view['dynamic_mask'] (the reference fails on torch.stack(None), optimizer.py:531)")
             fij, fji = flow
             self._flow = dict(flow_ij=torch.as_tensor(fij).float(), flow_ji=torch.as_tensor(fji).float(),
                               dyn=torch.stack(self.dynamic_masks), weight=float(flow_loss_weight), thre=float(flow_loss_thre),
                               start_epoch=float(flow_loss_start_epoch), num_total_iter=int(num_total_iter), pxl_thre=float(pxl_thre))
+
+    def get_motion_mask_from_pairs(self, view1, view2, pred1, pred2, flow_ij, flow_ji):
+        """cloud_opt_flow/optimizer.py:154-235: self-computed dynamic masks.  For every symmetric pair (e, e + E/2) a closed-form
+        PairViewer gives intrinsics, relative pose and depth; the ego-motion flow they imply is compared with the optical flow;
+        the per-pair error maps are min-max normalised, averaged per image and thresholded at motion_mask_thre.
+        Parity unpinned where PairViewer's PnP stand-in enters (cv2 absent); the flow geometry itself is pinned (goem_opt)."""
+        from ..cloud_opt.pair_viewer import PairViewer
+        from ..utils.goem_opt import DepthBasedWarping
+        assert self.is_symmetrized, 'only support symmetric case'
+        half = len(self.edges) // 2
+        K_i, K_j, R_i, R_j, T_i, T_j, D_i, D_j = [], [], [], [], [], [], [], []
+        p1, p2 = torch.as_tensor(pred1['pts3d']).float(), torch.as_tensor(pred2['pts3d_in_other_view']).float()
+        c1, c2 = torch.as_tensor(pred1['conf']).float(), torch.as_tensor(pred2['conf']).float()
+        for e in range(half):
+            pair = [e, e + half]
+            pv = PairViewer(dict(idx=[0, 1]), dict(idx=[1, 0]), dict(pts3d=p1[pair], conf=c1[pair]),
+                            dict(pts3d_in_other_view=p2[pair], conf=c2[pair]), verbose=False)
+            K, poses, depth = pv.get_intrinsics(), pv.get_im_poses(), pv.get_depthmaps()
+            K_i.append(K[0]); K_j.append(K[1])
+            R_i.append(poses[0][:3, :3]); R_j.append(poses[1][:3, :3])
+            T_i.append(poses[0][:3, 3:]); T_j.append(poses[1][:3, 3:])
+            D_i.append(depth[0]); D_j.append(depth[1])
+        dev = flow_ij.device
+        K_i, K_j, R_i, R_j, T_i, T_j = (torch.stack(x).to(dev) for x in (K_i, K_j, R_i, R_j, T_i, T_j))
+        D_i, D_j = torch.stack(D_i).unsqueeze(1).to(dev), torch.stack(D_j).unsqueeze(1).to(dev)
+        warp = DepthBasedWarping()
+        ego_1_2, _ = warp(R_i, T_i, R_j, T_j, 1 / (D_i + 1e-6), K_j, torch.linalg.inv(K_i))
+        ego_2_1, _ = warp(R_j, T_j, R_i, T_i, 1 / (D_j + 1e-6), K_i, torch.linalg.inv(K_j))
+        err_i = torch.norm(ego_1_2[:, :2] - flow_ij[:half], dim=1)
+        err_j = torch.norm(ego_2_1[:, :2] - flow_ji[:half], dim=1)
+        norm = lambda x: (x - x.amin(dim=(1, 2), keepdim=True)) / (x.amax(dim=(1, 2), keepdim=True) - x.amin(dim=(1, 2), keepdim=True))
+        err_i, err_j = norm(err_i), norm(err_j)
+        acc = [[] for _ in range(self.n_imgs)]
+        for e in range(half):
+            i, j = self.edges[e]
+            acc[i].append(err_i[e])
+            acc[j].append(err_j[e])
+        self.dynamic_masks = [(torch.stack(a).mean(dim=0) > self.motion_mask_thre).cpu() for a in acc]
 
     def to(self, device):
         device = torch.device(device)

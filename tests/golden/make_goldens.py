@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only -- /root/reference does not exist on the GPU box):
-    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow|prep|hier] [--out tests/golden]
+    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow|prep|hier|flowgeo] [--out tests/golden]
 
 What it does
   * puts /root/reference on sys.path (read-only, bytecode writing disabled) and imports the
@@ -625,6 +625,30 @@ def gen_hier(out):
     print("hier:", len(cases), "pair cases,", len(rule), "clip-size cases")
 
 
+def gen_flowgeo(out):
+    """dust3r/utils/goem_opt.py: DepthBasedWarping.forward (warp_by_disp) and OccMask on small random inputs."""
+    from dust3r.utils.goem_opt import DepthBasedWarping, OccMask
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 3, 10, 14
+    def rot(a, b):
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+        return np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]]) @ np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
+    R1 = torch.tensor(np.stack([rot(0.02 * k, -0.01 * k) for k in range(B)]), dtype=torch.float32)
+    R2 = torch.tensor(np.stack([rot(-0.03 * k, 0.02) for k in range(B)]), dtype=torch.float32)
+    t1, t2 = 0.1 * torch.randn(B, 3, 1, generator=g), 0.1 * torch.randn(B, 3, 1, generator=g)
+    disp = 0.2 + torch.rand(B, 1, H, W, generator=g)
+    K = torch.tensor([[12.0, 0, W / 2], [0, 12.0, H / 2], [0, 0, 1]]).repeat(B, 1, 1)
+    warp = DepthBasedWarping()
+    flow, coords = warp(R1, t1, R2, t2, disp, K, torch.linalg.inv(K))
+    f12, f21 = 2 * torch.randn(B, 2, H, W, generator=g), 2 * torch.randn(B, 2, H, W, generator=g)
+    f21c = -f12 + 0.5 * torch.randn(B, 2, H, W, generator=g)
+    occ = OccMask(th=3.0)
+    np.savez_compressed(os.path.join(out, "flowgeo.npz"), R1=R1.numpy(), R2=R2.numpy(), t1=t1.numpy(), t2=t2.numpy(), disp=disp.numpy(),
+                        K=K.numpy(), flow=flow.numpy(), coords=coords.numpy(), f12=f12.numpy(), f21=f21.numpy(), f21c=f21c.numpy(),
+                        occ_a=occ(f12, f21).numpy(), occ_b=occ(f12, f21c).numpy())
+    print("flowgeo: ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -632,7 +656,7 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(8)
     todo = [a.only] if a.only else ["pairs", "ops", "tiny", "vitl", "align", "alignflow"]
-    import_reference(aligner=any(t.startswith("align") or t in ("prep", "hier") for t in todo))
+    import_reference(aligner=any(t.startswith("align") or t in ("prep", "hier", "flowgeo") for t in todo))
     if "prep" in todo:
         _stub("imageio")
     for t in todo:

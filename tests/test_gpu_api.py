@@ -273,3 +273,44 @@ def test_pair_viewer_two_frames(model):
         global_aligner(dict(view1=dict(idx=[0]), view2=dict(idx=[1]), pred1=dict(pts3d=torch.from_numpy(p1[:1]), conf=torch.from_numpy(c[:1])),
                             pred2=dict(pts3d_in_other_view=torch.from_numpy(p2[:1]), conf=torch.from_numpy(c[:1]))),
                        False, [], "cuda", mode=GlobalAlignerMode.PairViewer, verbose=False)
+
+
+def test_self_computed_motion_masks(model):
+    """cloud_opt_flow use_self_mask=True (get_motion_mask_from_pairs, optimizer.py:154-235) with injected optical flow: on a
+    consistent scene whose flow is the true ego-motion flow except inside a rectangle that "moves", the self-computed dynamic
+    masks must flag that rectangle and little else, and the flow-regularised alignment must run."""
+    from dust3r.cloud_opt_flow import global_aligner
+    N, H, W = 3, 32, 48
+    edges, p1, p2, c, cams, depths, f = _geom_scene(N, H, W)
+    E = len(edges)
+    half = E // 2
+    # symmetric ordering required by the reference: edge e and e + E/2 are each other's reverse
+    fwd = [(i, j) for i, j in edges if i < j]
+    order = [edges.index(e) for e in fwd] + [edges.index((j, i)) for i, j in fwd]
+    edges = [edges[k] for k in order]; p1, p2, c = p1[order], p2[order], c[order]
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    def true_flow(i, j):
+        Ri, ti = cams[i]; Rj, tj = cams[j]
+        rays = np.stack([(xs - W / 2) / f, (ys - H / 2) / f, np.ones_like(xs)], -1)
+        world = (rays * depths[i][..., None]) @ Ri.T + ti
+        cam = (world - tj) @ Rj
+        u, v = f * cam[..., 0] / cam[..., 2] + W / 2, f * cam[..., 1] / cam[..., 2] + H / 2
+        return np.stack([u - xs, v - ys]).astype(np.float32)
+    fij = np.stack([true_flow(i, j) for i, j in edges])
+    fji = np.stack([true_flow(j, i) for i, j in edges])
+    moving = np.zeros((H, W), bool); moving[8:20, 10:26] = True
+    fij[:, :, moving] += 6.0                                          # an object moving 6 px on top of the ego motion, in every view
+    fji[:, :, moving] += 6.0
+    out = dict(view1=dict(idx=[i for i, j in edges]), view2=dict(idx=[j for i, j in edges]),
+               pred1=dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c)),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c)))
+    torch.manual_seed(0)
+    scene = global_aligner(out, "cuda", verbose=False, min_conf_thr=1.5, flow_loss_weight=0.01, use_self_mask=True, motion_mask_thre=0.35,
+                           flow=(torch.from_numpy(fij), torch.from_numpy(fji)), num_total_iter=20, flow_loss_start_epoch=0.0)
+    masks = [m.numpy() for m in scene.dynamic_masks]
+    assert len(masks) == N
+    for m in masks:
+        inter, union = (m & moving).sum(), (m | moving).sum()
+        assert inter / union > 0.6, inter / union
+    loss = scene.compute_global_alignment(init="mst", niter=20, schedule="linear", lr=0.01)
+    assert np.isfinite(loss)

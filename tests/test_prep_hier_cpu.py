@@ -182,3 +182,16 @@ def test_clean_pointcloud_matches_reference():
     for a, b in zip(out, want):
         assert torch.equal(a, b)
     assert all(torch.equal(a, t32(b)) for a, b in zip(conf, c["conf"]))   # inputs untouched
+
+
+def test_flow_geometry_matches_reference():
+    """DepthBasedWarping / OccMask (dust3r/utils/goem_opt.py) against the reference's outputs, bit for bit on the CPU."""
+    from align3r_amd.dust3r.utils.goem_opt import DepthBasedWarping, OccMask
+    g = np.load(os.path.join(GOLDEN, "flowgeo.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    K = t("K")
+    flow, coords = DepthBasedWarping()(t("R1"), t("t1"), t("R2"), t("t2"), t("disp"), K, torch.linalg.inv(K))
+    assert torch.equal(flow, t("flow")) and torch.equal(coords, t("coords"))
+    occ = OccMask(th=3.0)
+    assert torch.equal(occ(t("f12"), t("f21")), t("occ_a")) and torch.equal(occ(t("f12"), t("f21c")), t("occ_b"))
+    assert 0 < int(t("occ_b").sum()) < t("occ_b").numel()
