@@ -65,6 +65,11 @@ __device__ __forceinline__ float dpp_row_sum16(float v) {
     return v;
 }
 
+// value of the neighbouring lane (lane ^ 1) by DPP quad_perm [1,0,3,2]: one VALU op, no LDS crossbar (ds_bpermute)
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
 // full 64-lane sum (result valid in every lane)
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_row_sum16(v);

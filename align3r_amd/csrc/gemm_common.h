@@ -152,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue16_body(const GemmArgs& g, const Gr
                     for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
                 }
                 const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
-                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float r0 = dpp_xor1(s0), r1 = dpp_xor1(s1);
                 const float a0 = odd ? r0 : v[0], b0 = odd ? v[2] : r0;      // (left, right column) of this lane's first row
                 const float a1 = odd ? r1 : v[1], b1 = odd ? v[3] : r1;
                 const int row0 = m0 + wrow0 + i * 16 + quad * 4 + (odd ? 2 : 0);
