@@ -160,6 +160,9 @@ def main():
         "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "dtype_note": ("fp32 in / fp32 out / fp32 accumulate; products evaluated exactly from three-plane bf16 splits of both operands on the "
+                       "bf16 matrix cores (6 MFMA passes, error <= fp32 GEMM's: tests/test_gpu_bf3.py); A3R_GEMM=f32 selects v_mfma_f32_32x32x2_f32"
+                       if use_bf3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
         "config": {"workload": f"{a.frames}-frame synthetic clip {W}x{H}, ViT-L, {a.scene_graph} symmetrised (E={E}), "
                                f"{B} pairs/step/GPU, cloud_opt PointCloudOptimizer", "pairs_per_step_per_gpu": B,
                    "frames": a.frames, "edges": E, "parallelism": f"pair-shard x{world}" + (" + all-gather/step" if world > 1 else "")},
