@@ -314,3 +314,19 @@ def test_self_computed_motion_masks(model):
         assert inter / union > 0.6, inter / union
     loss = scene.compute_global_alignment(init="mst", niter=20, schedule="linear", lr=0.01)
     assert np.isfinite(loss)
+
+
+def test_inference_internal_batching_is_invisible(model, monkeypatch):
+    """inference(batch_size=1) (what every reference driver asks for) is run in larger launch plans internally; the outputs must be
+    bit-identical to an honest batch-of-one loop."""
+    from dust3r.image_pairs import make_pairs
+    from dust3r.inference import inference
+    views = _views(4, 48, 64, seed=7)
+    pairs = make_pairs(views, scene_graph="complete", symmetrize=True)
+    fast = inference(pairs, model, "cuda", batch_size=1, verbose=False)
+    monkeypatch.setenv("A3R_INFER_MIN_BATCH", "1")
+    slow = inference(pairs, model, "cuda", batch_size=1, verbose=False)
+    for side, keys in (("pred1", ("pts3d", "conf")), ("pred2", ("pts3d_in_other_view", "conf"))):
+        for k in keys:
+            assert torch.equal(fast[side][k], slow[side][k]), (side, k)
+    assert fast["view1"]["idx"] == slow["view1"]["idx"] and len(fast["view1"]["idx"]) == len(pairs)
