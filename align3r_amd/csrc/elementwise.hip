@@ -208,8 +208,64 @@ static inline int grid_for(long total, int block = 256) {
     return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
 
+// ------------------------------------------------------------------------------------------- weighted Umeyama moments
+// The raw second moments of B weighted point-set pairs (x_b, y_b, w_b), P points each, for the similarity registrations of the
+// aligner's initialisation (cloud_opt/init_im_poses.py:415-418: s R x + T ~ y): per problem and 1024-point chunk 17 doubles
+//   [0] sum w   [1..3] sum w x   [4..6] sum w y   [7] sum w |x|^2   [8..16] sum w y_r x_c (r major)
+// One launch for all problems (e.g. every edge of the pair graph); fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void umeyama_moments_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ w, const long* __restrict__ xo,
+                                                               const long* __restrict__ yo, const long* __restrict__ wo, int P,
+                                                               double* __restrict__ partial) {
+    __shared__ double red[4][17];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + xo[b];
+    const float* yb = y + yo[b];
+    const float* wb = w + wo[b];
+    double a[17];
+#pragma unroll
+    for (int j = 0; j < 17; j++) a[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = chunk * 1024 + i * 256 + tid;
+        if (p < P) {
+            const double ww = wb[p];
+            const double x0 = xb[3 * p], x1 = xb[3 * p + 1], x2 = xb[3 * p + 2];
+            const double y0 = yb[3 * p], y1 = yb[3 * p + 1], y2 = yb[3 * p + 2];
+            a[0] += ww;
+            a[1] += ww * x0; a[2] += ww * x1; a[3] += ww * x2;
+            a[4] += ww * y0; a[5] += ww * y1; a[6] += ww * y2;
+            a[7] += ww * (x0 * x0 + x1 * x1 + x2 * x2);
+            a[8] += ww * y0 * x0; a[9] += ww * y0 * x1; a[10] += ww * y0 * x2;
+            a[11] += ww * y1 * x0; a[12] += ww * y1 * x1; a[13] += ww * y1 * x2;
+            a[14] += ww * y2 * x0; a[15] += ww * y2 * x1; a[16] += ww * y2 * x2;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 17; j++) {
+        double v = a[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (tid < 17) partial[((size_t)b * gridDim.x + chunk) * 17 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 }  // namespace a3r
 using namespace a3r;
+
+extern "C" int a3r_umeyama_chunks(int P) { return P > 0 ? (P + 1023) / 1024 : 0; }
+
+extern "C" int a3r_umeyama_moments(const float* x, const float* y, const float* w, const long* x_off, const long* y_off,
+                                   const long* w_off, int B, int P, double* partial, void* stream) {
+    A3R_CHECK_ARG(x && y && w && x_off && y_off && w_off && partial, "a3r_umeyama_moments: null pointer");
+    A3R_CHECK_ARG(B > 0 && B <= 65535 && P > 0, "a3r_umeyama_moments: bad shape B=%d P=%d", B, P);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(umeyama_moments_kernel, dim3(a3r_umeyama_chunks(P), B), dim3(256), 0, st, x, y, w, x_off, y_off, w_off, P, partial);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
 
 template <bool BF3>
 static int launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps, void* stream) {

@@ -18,22 +18,61 @@ import torch
 from .commons import rotmat_to_unitquat, signed_log1p
 
 
+PNP_MAX_POINTS = 16384
+
 # ------------------------------------------------------------------------------------------------ small solvers
+def _solve_from_moments(m):
+    """[B,17] raw moments (float64, CPU) -> lists of (s, R float32 [3,3], T float32 [3]) : weighted Umeyama in closed form."""
+    m = m.double()
+    w0 = m[:, 0:1]
+    xm, ym = m[:, 1:4] / w0, m[:, 4:7] / w0
+    var_x = m[:, 7] / w0[:, 0] - xm.square().sum(-1)
+    cov = m[:, 8:17].reshape(-1, 3, 3) / w0[:, :, None] - ym[:, :, None] * xm[:, None, :]
+    U, S, Vt = torch.linalg.svd(cov)
+    d = torch.ones_like(S)
+    d[:, 2] = torch.sign(torch.det(U @ Vt))
+    R = (U * d[:, None, :]) @ Vt
+    s = (S * d).sum(-1) / var_x
+    T = ym - s[:, None] * torch.einsum('bij,bj->bi', R, xm)
+    return [(float(s[k]), R[k].float(), T[k].float()) for k in range(len(m))]
+
+
+def umeyama_moments(x, y, w, x_off, y_off, w_off, P):
+    """a3r_umeyama_moments over B problems on the device: x, y, w flat float32 device tensors, *_off int64 element offsets [B]
+    (device).  Returns the [B,17] float64 moments on the CPU (one synchronisation)."""
+    import ctypes as C
+    from ... import _lib
+    from ..._lib import check, ptr, stream_ptr
+    lib = _lib.load()
+    B = int(x_off.numel())
+    nch = int(lib.a3r_umeyama_chunks(P))
+    partial = torch.empty((B, nch, 17), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.a3r_umeyama_moments(ptr(x), ptr(y), ptr(w), ptr(x_off), ptr(y_off), ptr(w_off), B, P, ptr(partial), stream_ptr()),
+              "a3r_umeyama_moments")
+    return partial.sum(1).cpu()
+
+
 def rigid_points_registration(x, y, w):
-    """Weighted Umeyama: (s, R, T) minimising sum w |s R x + T - y|^2 for x, y [P,3], w [P]."""
-    x, y, w = x.reshape(-1, 3).double(), y.reshape(-1, 3).double(), w.reshape(-1).double()
-    w = w / w.sum()
-    xm, ym = (w[:, None] * x).sum(0), (w[:, None] * y).sum(0)
-    xc, yc = x - xm, y - ym
-    var_x = (w * xc.square().sum(-1)).sum()
-    cov = (yc * w[:, None]).T @ xc                           # 3x3
-    U, S, Vt = torch.linalg.svd(cov.cpu())
-    d = torch.ones(3, dtype=torch.float64)
-    d[2] = torch.sign(torch.det(U @ Vt))
-    R = (U * d) @ Vt
-    s = float((S * d).sum() / var_x.cpu())
-    T = ym.cpu() - s * (R @ xm.cpu())
-    return s, R.float(), T.float()
+    """Weighted Umeyama: (s, R, T) minimising sum w |s R x + T - y|^2 for x, y [P,3], w [P] (device float32 tensors or CPU:
+    the tiny camera-centre problems of align_multiple_poses stay on the host)."""
+    if not x.is_cuda:
+        x, y, w = x.reshape(-1, 3).double(), y.reshape(-1, 3).double(), w.reshape(-1).double()
+        m = torch.cat([w.sum()[None], (w[:, None] * x).sum(0), (w[:, None] * y).sum(0), (w * x.square().sum(-1)).sum()[None],
+                       torch.einsum('p,pi,pj->ij', w, y, x).reshape(9)])[None]
+        return _solve_from_moments(m)[0]
+    x, y, w = x.reshape(-1, 3).float().contiguous(), y.reshape(-1, 3).float().contiguous(), w.reshape(-1).float().contiguous()
+    zero = torch.zeros(1, dtype=torch.int64, device=x.device)
+    return _solve_from_moments(umeyama_moments(x, y, w, zero, zero, zero, x.shape[0]))[0]
+
+
+def rigid_points_registration_batched(X, Y, W, y_index):
+    """E registrations in one launch: X [E,P,3] against Y[y_index[e]] ([N,P,3]) with weights W [E,P] (contiguous float32, device)."""
+    E, P, _ = X.shape
+    dev = X.device
+    ar = torch.arange(E, device=dev, dtype=torch.int64)
+    yi = torch.as_tensor(y_index, device=dev, dtype=torch.int64)
+    return _solve_from_moments(umeyama_moments(X, Y, W, ar * (P * 3), yi * (P * 3), ar * P, P))
 
 
 def sRT_to_4x4(scale, R, T, device):
@@ -47,22 +86,28 @@ def geotrf(trf, pts):
     return pts @ trf[:3, :3].T + trf[:3, 3]
 
 
-def estimate_focal(pts3d_i):
-    """Weiszfeld focal of one pointmap [H,W,3] with the principal point at the centre (post_process.py:36-60)."""
-    H, W, _ = pts3d_i.shape
-    dev = pts3d_i.device
+def estimate_focals(pts3d):
+    """Weiszfeld focals of B pointmaps [B,H,W,3] with the principal point at the centre (post_process.py:36-60), batched on the
+    device: one synchronisation for all of them.  Returns a list of B floats."""
+    B, H, W, _ = pts3d.shape
+    dev = pts3d.device
     ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
-    pixels = torch.stack((xs - W / 2, ys - H / 2), -1).reshape(-1, 2).float()
-    p = pts3d_i.reshape(-1, 3)
-    xy_over_z = (p[:, :2] / p[:, 2:3]).nan_to_num(posinf=0, neginf=0)
+    pixels = torch.stack((xs - W / 2, ys - H / 2), -1).reshape(1, -1, 2).float()
+    p = pts3d.reshape(B, -1, 3)
+    xy_over_z = (p[..., :2] / p[..., 2:3]).nan_to_num(posinf=0, neginf=0)
     dot_xy_px = (xy_over_z * pixels).sum(-1)
     dot_xy_xy = xy_over_z.square().sum(-1)
-    focal = dot_xy_px.mean() / dot_xy_xy.mean()
+    focal = dot_xy_px.mean(-1) / dot_xy_xy.mean(-1)
     for _ in range(10):
-        dis = (pixels - focal * xy_over_z).norm(dim=-1)
+        dis = (pixels - focal[:, None, None] * xy_over_z).norm(dim=-1)
         wgt = dis.clip(min=1e-8).reciprocal()
-        focal = (wgt * dot_xy_px).mean() / (wgt * dot_xy_xy).mean()
-    return float(focal)
+        focal = (wgt * dot_xy_px).mean(-1) / (wgt * dot_xy_xy).mean(-1)
+    return focal.cpu().tolist()
+
+
+def estimate_focal(pts3d_i):
+    """One pointmap [H,W,3] -> focal."""
+    return estimate_focals(pts3d_i[None])[0]
 
 
 def linear_pnp(pts3d, focal, msk, pp=None, irls_rounds=2):
@@ -95,6 +140,9 @@ def linear_pnp(pts3d, focal, msk, pp=None, irls_rounds=2):
     pp = (W / 2, H / 2) if pp is None else pp
     rays = torch.stack(((xs - pp[0]) / focal, (ys - pp[1]) / focal, torch.ones_like(xs, dtype=torch.float32)), -1)[msk].double()
     X = pts3d[msk].double()
+    if len(X) > PNP_MAX_POINTS:          # a regular subsample is plenty for a 6-dof fit (the reference's RANSAC draws minimal sets)
+        step = -(-len(X) // PNP_MAX_POINTS)
+        rays, X = rays[::step], X[::step]
     Xh = torch.cat((X, torch.ones_like(X[:, :1])), -1)                       # [n,4]
     wgt = torch.ones(len(X), dtype=torch.float64, device=dev)
     best = None
@@ -150,6 +198,7 @@ def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_co
         graph[i, j] = -v
     msp = sp.csgraph.minimum_spanning_tree(graph).tocoo()
     todo = sorted(zip(-msp.data, msp.row.tolist(), msp.col.tolist()))
+    edge_focal = estimate_focals(pred_i) if has_im_poses else None      # every edge's Weiszfeld focal of its first view, one batch
     pts3d = [None] * n_imgs
     im_poses = [None] * n_imgs
     im_focals = [None] * n_imgs
@@ -169,7 +218,7 @@ def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_co
     if has_im_poses:
         if init_priors is None:
             im_poses[i] = torch.eye(4, device=device)
-            im_focals[i] = estimate_focal(pred_i[k])
+            im_focals[i] = edge_focal[k]
         else:
             keypose = torch.as_tensor(np.array(init_priors[0]).astype(np.float32), device=device)
             keyfocal = float(init_priors[2][0])
@@ -185,7 +234,7 @@ def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_co
     while todo:
         score, i, j = todo.pop()
         if im_focals[i] is None:
-            im_focals[i] = estimate_focal(pred_i[last_k])      # the reference uses the PREVIOUS edge's map here (:199)
+            im_focals[i] = edge_focal[last_k]      # the reference uses the PREVIOUS edge's map here (:199)
         if i in done:
             assert j not in done
             k = last_k = eidx[(i, j)]
@@ -210,7 +259,7 @@ def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_co
         order = sorted(scores.items(), key=lambda kv: -kv[1])
         for (i, j), _ in order:
             if im_focals[i] is None:
-                im_focals[i] = estimate_focal(pred_i[eidx[(i, j)]])
+                im_focals[i] = edge_focal[eidx[(i, j)]]
         for i in range(n_imgs):
             if im_poses[i] is None:
                 msk = (im_conf[i] > min_conf_thr).to(device)
@@ -239,11 +288,13 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
     if not eng.flags['train_poses']:
         raise NotImplementedError("init='mst' with preset poses (align_multiple_poses, init_im_poses.py:88-99)")
     pw = eng.params['pw_poses'].clone()
-    for e, (i, j) in enumerate(scene.edges):
-        s, R, T = rigid_points_registration(pred_i[e], pts3d[i], conf_i[e])
-        pw[e, 0:4] = rotmat_to_unitquat(R).to(dev)
-        pw[e, 4:7] = signed_log1p(T.to(dev) / s)
-        pw[e, 7] = float(np.log(s))
+    # all E pairwise registrations pred_i[e] -> pts3d[i] in ONE launch of the moments kernel + one batched 3x3 SVD
+    sols = rigid_points_registration_batched(pred_i.reshape(E, H * W, 3).float().contiguous(),
+                                             torch.stack([p.reshape(H * W, 3) for p in pts3d]).float().contiguous(),
+                                             conf_i.reshape(E, H * W).float().contiguous(), [i for i, _ in scene.edges])
+    pw[:, 0:4] = torch.stack([rotmat_to_unitquat(R) for _, R, _ in sols]).to(dev)
+    pw[:, 4:7] = signed_log1p(torch.stack([T / s for s, _, T in sols])).to(dev)
+    pw[:, 7] = torch.tensor([float(np.log(s)) for s, _, _ in sols], device=dev)
     s_factor = float(torch.exp(np.log(scene.base_scale) - pw[:, 7].mean())) if scene.norm_pw_scale else 1.0
     im_poses = im_poses.clone()
     im_poses[:, :3, 3] *= s_factor

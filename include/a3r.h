@@ -188,6 +188,14 @@ int a3r_patchify(const float* img, float* cols, int B, int C, int H, int W, long
 
 /* F.interpolate(scale_factor=2, bilinear, align_corners=True) on [B, H, W, C], writing only the
  * top-left Hc x Wc window of the 2H x 2W result (crop of dpt_head.py:57 folded in). C % 4 == 0. */
+/* Raw weighted second moments of B point-set pairs for the similarity registrations of the aligner's initialisation
+ * (cloud_opt/init_im_poses.py:415-418, roma.rigid_points_registration): problem b uses x + x_off[b], y + y_off[b] ([P,3] each) and
+ * w + w_off[b] ([P]) (element offsets, device int64).  partial [B][a3r_umeyama_chunks(P)][17] doubles:
+ * sum w | sum w x (3) | sum w y (3) | sum w |x|^2 | sum w y_r x_c (9, r major); the caller adds the chunks. */
+int a3r_umeyama_chunks(int P);
+int a3r_umeyama_moments(const float* x, const float* y, const float* w, const long* x_off, const long* y_off, const long* w_off,
+                        int B, int P, double* partial, void* stream);
+
 int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 /* the same, written in bf3 form ([B Hc Wc][C/8][3][8] bf16, C % 8 == 0): input of the next conv on the bf3 kernel */
 int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W, int C, int Hc, int Wc, void* stream);

@@ -212,3 +212,33 @@ def test_errors_are_loud(ops):
         ops.linear(rnd(4, 40), rnd(8, 40))
     with pytest.raises(RuntimeError):
         ops.linear(torch.zeros(4, 32), rnd(8, 32))      # CPU tensor
+
+
+def test_umeyama_moments_kernel():
+    """a3r_umeyama_moments (the registrations of the aligner's initialisation, init_im_poses.py:415-418): raw moments of B weighted
+    point-set pairs against float64 numpy, and the similarity recovered from them."""
+    from align3r_amd.dust3r.cloud_opt.init_im_poses import rigid_points_registration, rigid_points_registration_batched
+    rng = np.random.default_rng(0)
+    E, N, P = 5, 3, 3000
+    X = rng.standard_normal((E, P, 3)).astype(np.float32)
+    a = 0.4
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    Y = np.stack([(1.7 * X[e % N] @ R.T + np.array([0.3, -1.0, 2.0])) for e in range(N)]).astype(np.float32)
+    W = (0.5 + rng.random((E, P))).astype(np.float32)
+    yi = [e % N for e in range(E)]
+    sols = rigid_points_registration_batched(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), torch.from_numpy(W).cuda(), yi)
+    for e, (s, Rr, T) in enumerate(sols):
+        if e < N:            # x = X[e], y = similarity of X[e]: recovered exactly
+            assert abs(s - 1.7) < 1e-4 and np.abs(Rr.numpy() - R).max() < 1e-5 and np.abs(T.numpy() - [0.3, -1.0, 2.0]).max() < 1e-4
+        # against the float64 closed form on the host
+        x, y, w = X[e].astype(np.float64), Y[yi[e]].astype(np.float64), W[e].astype(np.float64)
+        w = w / w.sum()
+        xm, ym = (w[:, None] * x).sum(0), (w[:, None] * y).sum(0)
+        cov = ((y - ym) * w[:, None]).T @ (x - xm)
+        U, S, Vt = np.linalg.svd(cov)
+        d = np.array([1, 1, np.sign(np.linalg.det(U @ Vt))])
+        s_ref = (S * d).sum() / (w * ((x - xm) ** 2).sum(-1)).sum()
+        assert abs(s - s_ref) < 1e-5 * max(1, abs(s_ref))
+        assert np.abs(Rr.numpy() - (U * d) @ Vt).max() < 1e-5
+    s1, R1, T1 = rigid_points_registration(torch.from_numpy(X[0]).cuda(), torch.from_numpy(Y[0]).cuda(), torch.from_numpy(W[0]).cuda())
+    assert abs(s1 - sols[0][0]) < 1e-12 and torch.equal(R1, sols[0][1])          # same kernel, same order: bitwise
