@@ -33,8 +33,13 @@ def main(profile=False):
         out = scene(N, H, W, graph)
         torch.manual_seed(0)
         t0 = time.perf_counter()
+        if profile:
+            import cProfile, pstats
+            pr0 = cProfile.Profile(); pr0.enable()
         sc = global_aligner(out, False, [], "cuda", verbose=False, min_conf_thr=1.5)
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        if profile:
+            pr0.disable(); pstats.Stats(pr0).sort_stats("cumulative").print_stats(14)
         if profile:
             import cProfile, pstats
             pr = cProfile.Profile(); pr.enable()
