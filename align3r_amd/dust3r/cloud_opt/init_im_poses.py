@@ -102,7 +102,7 @@ def estimate_focals(pts3d):
         dis = (pixels - focal[:, None, None] * xy_over_z).norm(dim=-1)
         wgt = dis.clip(min=1e-8).reciprocal()
         focal = (wgt * dot_xy_px).mean(-1) / (wgt * dot_xy_xy).mean(-1)
-    return focal.cpu().tolist()
+    return focal.clip(min=0).cpu().tolist()          # post_process.py:60-61 with the defaults min_focal=0, max_focal=inf
 
 
 def estimate_focal(pts3d_i):

@@ -5,6 +5,8 @@ produce consistent geometry), so the test pins what the driver adds: clip cuttin
 (every clip must land in the keyframes' world frame) and the output files.  MST init is parity-unpinned (roma / cv2 absent)
 and is validated by its purpose, as in test_gpu_api.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,3 +97,56 @@ def test_hierarchical_alignment_chains_clips_into_the_keyframe_frame(monkeypatch
     assert len(list(tmp_path.glob("conf_*.npy"))) == N
     with pytest.raises(ValueError, match="at least 3 frames"):
         hz.hierarchical_alignment(imgs[:2], None, "cuda")
+
+
+def test_run_clip_end_to_end_from_files(tmp_path, monkeypatch):
+    """align3r_amd.tool.run_clip: PNG frames + mono-depth .npz on disk -> load_images -> checkpoint -> make_pairs -> [pair forward]
+    -> HIP aligner (init='mst') -> output files + depth metrics.  The pair forward is run for real (TINY random weights) to
+    exercise the plumbing, then its pointmaps are replaced by geometrically consistent ones (random weights cannot produce a
+    scene the initialisation could make sense of -- the reference's own init yields focal 0 there too)."""
+    import PIL.Image
+    import align3r_amd
+    align3r_amd.install_as_dust3r()
+    import align3r_amd.dust3r.inference as inf_mod
+    from dust3r.model import AsymmetricCroCo3DStereo, _parse_model_string, save_checkpoint
+    from align3r_amd.weights import TINY, model_string
+    from align3r_amd.tool import run_clip
+    rng = np.random.RandomState(3)
+    frames, gt = tmp_path / "frames", tmp_path / "gt"
+    frames.mkdir(); gt.mkdir()
+    N, H, W = 4, 48, 64
+    cams, world, f = _scene(N, H, W)
+    for i in range(N):
+        PIL.Image.fromarray(rng.randint(0, 256, (60, 80, 3)).astype(np.uint8)).save(frames / f"f_{i:03d}.png")
+        np.savez(frames / f"f_{i:03d}_pred_depth_depthpro.npz", depth=(1 + rng.rand(60, 80)).astype(np.float32), focallength_px=np.float32(70.0))
+        np.save(gt / f"f_{i:03d}.npy", (((world[i] - cams[i][1]) @ cams[i][0])[..., 2]).astype(np.float32))     # true depth
+    kw = _parse_model_string(model_string(TINY))
+    ckpt = str(tmp_path / "tiny.pth")
+    save_checkpoint(ckpt, AsymmetricCroCo3DStereo(**{**kw, "landscape_only": False}))
+    real_inference = inf_mod.inference
+    seen = {}
+
+    def inference_then_consistent_geometry(pairs, model, device, **kw):
+        out = real_inference(pairs, model, device, **kw)                  # the HIP forward on the loaded frames
+        seen["shape"] = tuple(out["pred1"]["pts3d"].shape)
+        assert torch.isfinite(out["pred1"]["pts3d"]).all() and (out["pred1"]["conf"] >= 1).all()
+        gi = [int(os.path.basename(a["instance"])[2:5]) for a, b in pairs]
+        gj = [int(os.path.basename(b["instance"])[2:5]) for a, b in pairs]
+        p1 = np.stack([0.7 * ((world[i] - cams[i][1]) @ cams[i][0]) for i in gi]).astype(np.float32)
+        p2 = np.stack([0.7 * ((world[j] - cams[i][1]) @ cams[i][0]) for i, j in zip(gi, gj)]).astype(np.float32)
+        out["pred1"]["pts3d"], out["pred2"]["pts3d_in_other_view"] = torch.from_numpy(p1), torch.from_numpy(p2)
+        out["pred1"]["conf"] = out["pred2"]["conf"] = torch.full((len(pairs), H, W), 5.0)
+        return out
+
+    monkeypatch.setattr(inf_mod, "inference", inference_then_consistent_geometry)
+    torch.manual_seed(0)
+    res = run_clip.main(["--images", str(frames), "--weights", ckpt, "--out", str(tmp_path / "out"), "--size", "64", "--niter", "30",
+                         "--scene-graph", "complete", "--min-conf-thr", "1.5", "--gt-depth", str(gt), "--quiet"])
+    assert seen["shape"] == (12, H, W, 3)
+    assert res["n_frames"] == N and res["metrics"]["n_valid"] == N * H * W
+    assert res["metrics"]["abs_rel"] < 0.02 and res["metrics"]["d1"] > 0.99          # aligned depth = true depth up to scale/shift
+    out = tmp_path / "out"
+    assert len((out / "pred_traj.txt").read_text().splitlines()) == N
+    assert sorted(p.name for p in out.glob("frame_*.npy")) == [f"frame_{i:04d}.npy" for i in range(N)]
+    d = np.load(out / "frame_0002.npy")
+    assert d.shape == (H, W) and np.isfinite(d).all() and (d > 0).all()
