@@ -81,41 +81,36 @@ def make_pairs(imgs, scene_graph='complete', prefilter=None, symmetrize=True):
 
 
 def sel(x, kept):
+    """Keep the entries `kept` of every array / tensor / sequence found in a nested dict (anything else maps to None)."""
     if isinstance(x, dict):
-        return {k: sel(v, kept) for k, v in x.items()}
-    if isinstance(x, np.ndarray) or (torch is not None and isinstance(x, torch.Tensor)):
+        return {name: sel(value, kept) for name, value in x.items()}
+    is_array = isinstance(x, np.ndarray) or (torch is not None and isinstance(x, torch.Tensor))
+    if is_array:
         return x[kept]
     if isinstance(x, (tuple, list)):
-        return type(x)([x[k] for k in kept])
+        return type(x)([x[index] for index in kept])
+    return None
+
+
+def _temporal_distance(i, j, n, cyclic):
+    d = abs(i - j)
+    return min(d, abs(i + n - j), abs(i - n - j)) if cyclic else d
 
 
 def _filter_edges_seq(edges, seq_dis_thr, cyclic=False):
-    n = max(max(e) for e in edges) + 1       # ValueError on an empty edge list, like the reference (:89)
-    kept = []
-    for e, (i, j) in enumerate(edges):
-        dis = abs(i - j)
-        if cyclic:
-            dis = min(dis, abs(i + n - j), abs(i - n - j))
-        if dis <= seq_dis_thr:
-            kept.append(e)
-    return kept
+    """Indices of the edges whose frames are at most seq_dis_thr apart (around the ring of n = max index + 1 frames if cyclic)."""
+    n = 1 + max(max(edge) for edge in edges)       # ValueError on an empty edge list, like the reference (:89)
+    return [index for index, (i, j) in enumerate(edges) if _temporal_distance(i, j, n, cyclic) <= seq_dis_thr]
 
 
 def filter_pairs_seq(pairs, seq_dis_thr, cyclic=False):
-    edges = [(a['idx'], b['idx']) for a, b in pairs]
-    return [pairs[k] for k in _filter_edges_seq(edges, seq_dis_thr, cyclic=cyclic)]
+    keep = _filter_edges_seq([(a['idx'], b['idx']) for a, b in pairs], seq_dis_thr, cyclic=cyclic)
+    return [pairs[index] for index in keep]
 
 
 def filter_edges_seq(view1, view2, pred1, pred2, seq_dis_thr, cyclic=False):
-    edges = [(int(i), int(j)) for i, j in zip(view1['idx'], view2['idx'])]
-    kept = _filter_edges_seq(edges, seq_dis_thr, cyclic=cyclic)
-    print(f'>> Filtering edges more than {seq_dis_thr} frames apart: kept {len(kept)}/{len(edges)} edges')
-    return sel(view1, kept), sel(view2, kept), sel(pred1, kept), sel(pred2, kept)
-
-
-def shard_pairs(n_pairs: int, rank: int, world_size: int):
-    """Contiguous shard [lo, hi) of the pair list for `rank` (pair sharding across GPUs).
-    Shards differ in size by at most one pair; every rank computes the same split from the same list."""
-    base, rem = divmod(n_pairs, world_size)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """The same filter applied to an inference() result (image_pairs.py:99-104)."""
+    edges = list(zip(map(int, view1['idx']), map(int, view2['idx'])))
+    keep = _filter_edges_seq(edges, seq_dis_thr, cyclic=cyclic)
+    print(f'>> Filtering edges more than {seq_dis_thr} frames apart: kept {len(keep)}/{len(edges)} edges')
+    return tuple(sel(part, keep) for part in (view1, view2, pred1, pred2))
