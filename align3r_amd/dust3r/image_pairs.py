@@ -114,3 +114,11 @@ def filter_edges_seq(view1, view2, pred1, pred2, seq_dis_thr, cyclic=False):
     keep = _filter_edges_seq(edges, seq_dis_thr, cyclic=cyclic)
     print(f'>> Filtering edges more than {seq_dis_thr} frames apart: kept {len(keep)}/{len(edges)} edges')
     return tuple(sel(part, keep) for part in (view1, view2, pred1, pred2))
+
+
+def shard_pairs(n_pairs: int, rank: int, world_size: int):
+    """Contiguous shard [lo, hi) of the pair list for `rank` (pair sharding across GPUs).
+    Shards differ in size by at most one pair; every rank computes the same split from the same list."""
+    base, rem = divmod(n_pairs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
