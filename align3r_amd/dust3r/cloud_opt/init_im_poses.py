@@ -90,6 +90,8 @@ def estimate_focals(pts3d):
     """Weiszfeld focals of B pointmaps [B,H,W,3] with the principal point at the centre (post_process.py:36-60), batched on the
     device: one synchronisation for all of them.  Returns a list of B floats."""
     B, H, W, _ = pts3d.shape
+    if B > 256:                                   # bound the temporaries (a complete 64-frame graph has 4032 pointmaps)
+        return [f for k in range(0, B, 256) for f in estimate_focals(pts3d[k:k + 256])]
     dev = pts3d.device
     ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
     pixels = torch.stack((xs - W / 2, ys - H / 2), -1).reshape(1, -1, 2).float()
