@@ -47,7 +47,6 @@ def test_tiny_vs_reference_golden(tiny_engine, tag, H, W):
     B, N = 2, (H // 16) * (W // 16)
     feat = host(tiny_engine.tap("feat", TINY.enc_embed_dim)).reshape(2, B, N, -1)
     assert rel_err(feat[0, :1], t[f"{tag}_enc1"]) < TOL
-    assert rel_err(host(tiny_engine.tap("hook_a", TINY.dec_embed_dim)).reshape(2, B, N, -1)[0, :1], t[f"{tag}_dec1_6"][:1]) < TOL or True
     last = host(tiny_engine.tap("dec_last", TINY.dec_embed_dim)).reshape(2, B, N, -1)
     assert rel_err(last[0, :1], t[f"{tag}_dec1_last"]) < TOL
     assert rel_err(last[1, :1], t[f"{tag}_dec2_last"]) < TOL
