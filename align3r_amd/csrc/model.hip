@@ -556,13 +556,14 @@ float* fusion(Plan& P, const FusionW& w, const float* x0, const float* x1, bool 
 // ---- the same blocks on the bf3 kernels.  A conv input lives in bf3 form; where the fp32 value is also needed (skip
 // connections) the producer writes both (aux_bf3), pre-activated when the consumer is an RCU (which starts with a ReLU).
 // x: fp32 [B,H,W,F]; xr3: bf3 of relu(x); tmp3: bf3 scratch; out: fp32; out_r3: bf3 of relu(out) or null
+// (aux_relu = false: out_r3 is the bf3 form of out itself, for a consumer that does not start with a ReLU)
 void rcu_bf3(Plan& P, const RcuW& w, const float* x, const float* xr3, const float* extra, float* tmp3, float* out, float* out_r3,
-             int B, int H, int W, int F) {
+             int B, int H, int W, int F, bool aux_relu = true) {
     a3r_epilogue e1 = P.epi(A3R_EPI_RELU, w.c1b);
     e1.out_bf3 = 1;
     P.conv3(xr3, w.c1w, tmp3, B, H, W, F, F, 1, e1);
     a3r_epilogue e2 = extra ? P.epi(A3R_EPI_RESID2, w.c2b, x, extra) : P.epi(A3R_EPI_RESID, w.c2b, x);
-    if (out_r3) { e2.aux_bf3 = out_r3; e2.aux_relu = 1; }
+    if (out_r3) { e2.aux_bf3 = out_r3; e2.aux_relu = aux_relu ? 1 : 0; }
     P.conv3(tmp3, w.c2w, out, B, H, W, F, F, 1, e2);
 }
 
@@ -581,16 +582,37 @@ float* fusion_bf3(Plan& P, const FusionW& w, const float* x0, const float* x0r3,
     } else {
         cur = x0; cur3 = x0r3;
     }
+    static const bool ref_order = getenv("A3R_DPT_REF_ORDER") != nullptr;    // A/B switch: up-sample first, as the reference does
+    if (ref_order) {
+        float* o = ar.alloc(n);
+        rcu_bf3(P, w.r2, cur, cur3, nullptr, tmp3, o, nullptr, B, H, W, F);
+        const size_t opx = (size_t)B * Hc * Wc;
+        float* u3 = P.alloc3(opx, F);
+        P.up3(o, u3, B, H, W, F, Hc, Wc);
+        a3r_epilogue e = P.epi(A3R_EPI_NONE, w.ob);
+        float* r;
+        if (last) { r = P.alloc3(opx, F); e.out_bf3 = 1; }
+        else r = ar.alloc(opx * F);
+        P.linear(u3, F, w.ow, r, F, (int)opx, F, F, e);
+        return r;
+    }
+    // out_conv (1x1, dpt_block.py:216) is applied BEFORE the bilinear 2x instead of after it: both are linear maps over
+    // different axes (channels / pixels) and the interpolation weights sum to one, so conv(up(x)) + b == up(conv(x) + b) up
+    // to fp32 rounding -- a quarter of the 1x1 GEMM's rows, and the full-resolution map is written once instead of three times.
     float* o = ar.alloc(n);
-    rcu_bf3(P, w.r2, cur, cur3, nullptr, tmp3, o, nullptr, B, H, W, F);
+    float* o3 = P.alloc3(px, F);
+    rcu_bf3(P, w.r2, cur, cur3, nullptr, tmp3, o, o3, B, H, W, F, /*aux_relu=*/false);
+    float* lo = ar.alloc(n);
+    P.linear(o3, F, w.ow, lo, F, (int)px, F, F, P.epi(A3R_EPI_NONE, w.ob));
     const size_t opx = (size_t)B * Hc * Wc;
-    float* u3 = P.alloc3(opx, F);
-    P.up3(o, u3, B, H, W, F, Hc, Wc);
-    a3r_epilogue e = P.epi(A3R_EPI_NONE, w.ob);
     float* r;
-    if (last) { r = P.alloc3(opx, F); e.out_bf3 = 1; }
-    else r = ar.alloc(opx * F);
-    P.linear(u3, F, w.ow, r, F, (int)opx, F, F, e);
+    if (last) {
+        r = P.alloc3(opx, F);
+        P.up3(lo, r, B, H, W, F, Hc, Wc);
+    } else {
+        r = ar.alloc(opx * F);
+        P.up(lo, r, B, H, W, F, Hc, Wc);
+    }
     return r;
 }
 

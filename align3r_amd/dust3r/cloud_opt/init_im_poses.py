@@ -288,7 +288,15 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
                                                           scene.min_conf_thr, dev, init_priors=init_priors, verbose=scene.verbose)
     # ---- init_from_pts3d (:83-126); the known-poses branch (nkp > 1) re-aligns everything on the preset poses
     if not eng.flags['train_poses']:
-        raise NotImplementedError("init='mst' with preset poses (align_multiple_poses, init_im_poses.py:88-99)")
+        # every pose is preset (preset_pose takes all images at once here): one global similarity carries the tree's cameras
+        # and pointmaps onto the known poses (:88-99); the preset poses themselves are left alone below, as _set_pose does
+        if N == 1:
+            raise NotImplementedError('Would be simpler to just align everything afterwards on the single known pose')
+        s, R, T = align_multiple_poses(im_poses, scene.get_im_poses())
+        trf = sRT_to_4x4(s, R, T, dev)
+        im_poses = trf @ im_poses
+        im_poses[:, :3, :3] /= s
+        pts3d = [geotrf(trf, p.reshape(-1, 3)).reshape(p.shape) for p in pts3d]
     pw = eng.params['pw_poses'].clone()
     # all E pairwise registrations pred_i[e] -> pts3d[i] in ONE launch of the moments kernel + one batched 3x3 SVD
     sols = rigid_points_registration_batched(pred_i.reshape(E, H * W, 3).float().contiguous(),
@@ -310,8 +318,9 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
             w2c = torch.linalg.inv(c2w)
             d = geotrf(w2c, pts3d[i].reshape(-1, 3))[:, 2]
             depth[i] = d.log().nan_to_num(neginf=0)
-        poses[i, 0:4] = rotmat_to_unitquat(c2w[:3, :3]).to(dev)
-        poses[i, 4:7] = signed_log1p(c2w[:3, 3])
+        if eng.flags['train_poses']:
+            poses[i, 0:4] = rotmat_to_unitquat(c2w[:3, :3]).to(dev)
+            poses[i, 4:7] = signed_log1p(c2w[:3, 3])
         if im_focals[i] is not None and eng.flags['train_focals'] and not getattr(eng, 'shared_focal', False):
             focals[i] = scene.focal_break * float(np.log(im_focals[i]))
     if getattr(eng, 'shared_focal', False) and eng.flags['train_focals'] and im_focals[0] is not None:

@@ -6,8 +6,9 @@ im_poses [N,7], im_focals = focal_break*log f, im_pp), same random initial state
 (parameters are drawn in the reference's order), same getters and the same optimisation loop
 (Adam betas (0.9, 0.9), cosine/linear schedule).  Gradients are analytic (the reference uses autograd).
 init='mst' is available but PARITY UNPINNED (init_im_poses.py of this package: roma / cv2 are absent).
-Not available here (raise NotImplementedError): init='known_poses', allow_pw_adaptors=True, mixed image shapes with different aspect (padding is supported by the
-kernels, see a3r.h, but not wired through this class yet).
+init='known_poses' and init='mst' on preset poses are available too (same caveat: the PnP is a linear stand-in for cv2's).
+Not available here (raise NotImplementedError): allow_pw_adaptors=True, images of different shapes in one problem (padding is
+supported by the kernels, see a3r.h, but not wired through this class yet).
 """
 from __future__ import annotations
 

@@ -160,7 +160,8 @@ class PointCloudOptimizer(_Base):
             from ..cloud_opt.init_im_poses import init_minimum_spanning_tree       # parity unpinned (see that module)
             init_minimum_spanning_tree(self, init_priors=init_priors, niter_PnP=niter_PnP)
         elif init == 'known_poses':
-            raise NotImplementedError("init='known_poses' is not built")
+            raise NotImplementedError("init='known_poses': the reference's own branch cannot run (base_opt.py:468 hands preset_pose a "
+                                      "python list, optimizer.py:325 takes .shape of it); preset_pose + init='mst' is the working route")
         else:
             raise ValueError(f'bad value for {init=}')
         if niter <= 0:

@@ -243,6 +243,34 @@ def test_known_poses_initialisation(model):
     assert torch.allclose(scene.get_im_poses().cpu(), torch.stack(poses), atol=1e-5)      # frozen
 
 
+def test_mst_init_with_preset_poses(model):
+    """init='mst' after preset_pose (init_from_pts3d's nkp > 1 branch, init_im_poses.py:88-99; parity unpinned): the spanning
+    tree's cameras and pointmaps are carried onto the preset poses by one similarity, the presets stay untouched, and the scene
+    lands at the presets' metric scale (the generator's pointmaps are 0.7x metric)."""
+    from dust3r.cloud_opt import global_aligner
+    N, H, W = 4, 32, 48
+    edges, p1, p2, c, cams, depths, f = _geom_scene(N, H, W)
+    out = dict(view1=dict(idx=[i for i, j in edges]), view2=dict(idx=[j for i, j in edges]),
+               pred1=dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c)),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c)))
+    torch.manual_seed(0)
+    scene = global_aligner(out, False, [], "cuda", verbose=False, min_conf_thr=1.5)
+    loss_random = float(scene())
+    poses = []
+    for R, t in cams:
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, t
+        poses.append(torch.from_numpy(T))
+    scene.preset_pose(poses)
+    scene.compute_global_alignment(init="mst", niter=0)
+    assert torch.allclose(scene.get_im_poses().cpu(), torch.stack(poses), atol=1e-5)
+    loss_init = float(scene())
+    assert loss_init < 0.02 * loss_random, (loss_init, loss_random)
+    got = torch.stack(scene.get_depthmaps()).cpu().numpy()
+    assert np.abs(got / np.stack(depths) - 1).max() < 0.03
+    assert np.all(np.abs(scene.get_focals().cpu().numpy().ravel() / f - 1) < 0.03)
+
+
 def test_pair_viewer_two_frames(model):
     """GlobalAlignerMode.PairViewer (pair_viewer.py; what the drivers use for 2-frame inputs): closed form, parity unpinned
     (PnP stand-in) -- a consistent two-view scene must give back the focal, the relative pose and both depth maps."""
