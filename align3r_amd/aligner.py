@@ -91,6 +91,7 @@ class AlignEngine:
             self.flow["flow_ji"] = f32(flow["flow_ji"]).reshape(E, 2, P)
             self.flow["dyn"] = torch.as_tensor(np.ascontiguousarray(flow["dyn"])).reshape(N, P).to(dev, torch.uint8).contiguous()
         self.flow_variant = self.shared_focal or self.tsw > 0 or self.flow is not None
+        self.prior = None             # set_depth_prior(): dict(weight, init [N,P], dyn [N,P] uint8 | None, workspace)
         self.params = dict(pw_poses=z(E, 8), pw_adaptors=z(E, 2), depth=z(N, P), shifts=z(N), im_poses=z(N, 7),
                            im_focals=z(1 if self.shared_focal else N), im_pp=z(N, 2))
         self.flow_workspace = (torch.empty(int(self.lib.a3r_align_flow_workspace_bytes(E, N, P)), dtype=torch.uint8, device=dev)
@@ -144,6 +145,12 @@ class AlignEngine:
                     f.dynamic_mask = fl["dyn"].data_ptr()
                 f.workspace, f.workspace_bytes = self.flow_workspace.data_ptr(), self.flow_workspace.numel()
                 check(self.lib.a3r_align_set_flow(h, C.byref(f), stream_ptr()), "a3r_align_set_flow")
+            if self.prior is not None:
+                pr = self.prior
+                check(self.lib.a3r_align_set_depth_prior(h, float(pr["weight"]), pr["init"].data_ptr(),
+                                                         pr["dyn"].data_ptr() if pr["dyn"] is not None else None,
+                                                         pr["workspace"].data_ptr(), pr["workspace"].numel(), stream_ptr()),
+                      "a3r_align_set_depth_prior")
         self.handle = h
 
     def __del__(self):
@@ -170,6 +177,26 @@ class AlignEngine:
             self._create()     # step counter restarts with fresh Adam moments
         else:
             check(self.lib.a3r_align_invalidate(self.handle))
+
+    def set_depth_prior(self, weight, dyn=None, init=None):
+        """depth_regularize_weight of the flow variant (optimizer.py:546-555).  `init`: [N,P] log-depth parameters to regularise
+        towards (default: a copy of the current ones, which is what _set_init_depthmap captures); `dyn`: [N,P] dynamic masks."""
+        if weight <= 0:
+            self.prior = None
+        else:
+            if self.use_mono:
+                raise RuntimeError("the depth prior belongs to the flow variant, which has no mono-depth parameterisation")
+            init = self.params["depth"].clone() if init is None else torch.as_tensor(init, dtype=torch.float32).to(self.device).reshape(self.N, self.P).contiguous()
+            if dyn is not None:
+                dyn = torch.as_tensor(np.ascontiguousarray(dyn)).reshape(self.N, self.P).to(self.device, torch.uint8).contiguous()
+            ws = torch.empty(int(self.lib.a3r_align_depth_prior_workspace_bytes(self.N, self.P)), dtype=torch.uint8, device=self.device)
+            self.prior = dict(weight=float(weight), init=init, dyn=dyn, workspace=ws)
+        with torch.cuda.device(self.device):
+            pr = self.prior
+            check(self.lib.a3r_align_set_depth_prior(self.handle, float(pr["weight"]) if pr else 0.0, pr["init"].data_ptr() if pr else None,
+                                                     pr["dyn"].data_ptr() if pr and pr["dyn"] is not None else None,
+                                                     pr["workspace"].data_ptr() if pr else None, pr["workspace"].numel() if pr else 0,
+                                                     stream_ptr()), "a3r_align_set_depth_prior")
 
     def set_trainable(self, **flags):
         """preset_pose / preset_focal / preset_principal_point semantics (optimizer.py:76-113)."""

@@ -52,6 +52,11 @@ struct AlignDev {
     float *partF, *sumF;              // [2E, nchunks, 20], [2E, 20]
     float *flow_state;                // [8]: c0, c1, flow_loss, dropped_now, dropped_sticky
     float *lossN;                     // [N] temporal-smoothing loss of the pair (n, n+1)
+    // depth prior of cloud_opt_flow (a3r_align_set_depth_prior); weight 0 / null otherwise
+    float prior_w;
+    const float* prior_init;          // [N, P] log-depth parameters at the time of _set_init_depthmap
+    const unsigned char* prior_dyn;   // [N, P] 1 = dynamic pixel (weight 2), may be null (all weights 1)
+    float *gprior, *lossP;            // [N, P] d(weighted prior)/d(log-depth parameter); [N] per-image prior loss
 };
 
 struct AdamArgs {
@@ -395,6 +400,11 @@ __global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
         accN[15] += gd;
         gout[i] = gd * ddp;
     }
+    if (MODE != 0 && d.gprior) {      // depth prior (align_depth_prior_kernel): already w.r.t. the log-depth parameter
+#pragma unroll
+        for (int i = 0; i < PXT; i++)
+            if (valid[i]) gout[i] += d.gprior[(size_t)n * P + pix0 + i * PSTEP];
+    }
     const size_t NP = (size_t)d.N * P;
     if (VEC) {
         if (valid[0]) {
@@ -440,6 +450,57 @@ __global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) s += red[0][0][r][tid];
         d.partN[((size_t)n * d.nchunks + chunk) * 16 + tid] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- depth prior (cloud_opt_flow)
+// depth_regularization_si_weighted (goem_opt.py:15-36) as optimizer.py:546-555 calls it: per image, with l = log clamp(depth, 1e-6),
+// l0 the same of the initial depth map and w = 1 + dynamic_mask,
+//     scale = sum(l0 - l) / HW,    loss_n = sum w (l - l0 + scale)^2 / HW,    prior = mean_n loss_n.
+// One workgroup per image: pass 1 the four sums (fp64, fixed order), pass 2 the gradient w.r.t. the log-depth parameter, the
+// dependence through `scale` included:  d loss_n / d l_q = (2 / HW) (w_q r_q - sum_p w_p r_p / HW).
+constexpr int PRIOR_TPB = 1024;
+constexpr float PRIOR_EPS = 1e-6f;
+__global__ __launch_bounds__(PRIOR_TPB) void align_depth_prior_kernel(AlignDev d) {
+    __shared__ double sh[4][PRIOR_TPB / 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int area = d.imarea[n];
+    const float* raw = d.depth + (size_t)n * d.P;
+    const float* raw0 = d.prior_init + (size_t)n * d.P;
+    const unsigned char* dyn = d.prior_dyn ? d.prior_dyn + (size_t)n * d.P : nullptr;
+    auto logd = [](float r) { return logf(fmaxf(expf(r), PRIOR_EPS)); };
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};        // sum delta, sum w delta, sum w delta^2, sum w
+    for (int p = tid; p < area; p += PRIOR_TPB) {
+        const float delta = logd(raw[p]) - logd(raw0[p]);
+        const float w = (dyn && dyn[p]) ? 2.f : 1.f;
+        acc[0] += delta; acc[1] += w * delta; acc[2] += (double)w * delta * delta; acc[3] += w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+        if ((tid & 63) == 0) sh[k][tid >> 6] = acc[k];
+    }
+    __syncthreads();
+    double tot[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        tot[k] = 0.0;
+        for (int w = 0; w < PRIOR_TPB / 64; w++) tot[k] += sh[k][w];
+    }
+    const double inv = 1.0 / (double)area;
+    const double scale = -tot[0] * inv;
+    const double swr = tot[1] + scale * tot[3];                    // sum w (delta + scale)
+    if (tid == 0) d.lossP[n] = (float)((tot[2] + 2.0 * scale * tot[1] + scale * scale * tot[3]) * inv);
+    const float coef = d.prior_w / (float)d.N * 2.f * (float)inv, fscale = (float)scale, mean_wr = (float)(swr * inv);
+    float* g = d.gprior + (size_t)n * d.P;
+    for (int p = tid; p < d.P; p += PRIOR_TPB) {
+        float v = 0.f;
+        if (p < area && expf(raw[p]) > PRIOR_EPS) {                // the clamp passes no gradient below eps
+            const float delta = logd(raw[p]) - logd(raw0[p]);
+            const float w = (dyn && dyn[p]) ? 2.f : 1.f;
+            v = coef * (w * (delta + fscale) - mean_wr);
+        }
+        g[p] = v;
     }
 }
 
@@ -777,6 +838,11 @@ __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamA
     if (tid == 0) {
         if (d.tsw > 0.f) for (int n = 0; n + 1 < d.N; n++) loss += (double)d.lossN[n];
         if (d.flow_on && d.flow_state[3] == 0.f) loss += (double)d.flow_w * d.flow_state[2];
+        if (d.prior_w > 0.f) {
+            double lp = 0.0;
+            for (int n = 0; n < d.N; n++) lp += (double)d.lossP[n];
+            loss += (double)d.prior_w * lp / d.N;
+        }
         if (MODE == 2) d.loss_history[ad.step] = (float)loss;
         else *loss_out = (float)loss;
     }
@@ -1027,9 +1093,35 @@ extern "C" int a3r_align_set_flow(a3r_align_t a, const a3r_align_flow_desc* f, v
     return A3R_OK;
 }
 
+extern "C" size_t a3r_align_depth_prior_workspace_bytes(int N, int P) {
+    return align_up((size_t)N * P * 4, 256) + align_up((size_t)N * 4, 256);
+}
+
+extern "C" int a3r_align_set_depth_prior(a3r_align_t a, float weight, const float* init_log_depth, const unsigned char* dynamic_mask,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    A3R_CHECK_ARG(a, "a3r_align_set_depth_prior: null handle");
+    A3R_CHECK_ARG(weight >= 0.f, "a3r_align_set_depth_prior: negative weight");
+    AlignDev& d = a->d;
+    if (weight == 0.f) {
+        d.prior_w = 0.f; d.prior_init = nullptr; d.prior_dyn = nullptr; d.gprior = nullptr; d.lossP = nullptr;
+        return A3R_OK;
+    }
+    A3R_CHECK_ARG(!a->use_mono, "a3r_align_set_depth_prior: the flow variant has no mono-depth parameterisation");
+    A3R_CHECK_ARG(init_log_depth, "a3r_align_set_depth_prior: the initial depth maps are missing (_set_init_depthmap has not run)");
+    const size_t need = a3r_align_depth_prior_workspace_bytes(d.N, d.P);
+    A3R_CHECK_ARG(workspace && workspace_bytes >= need, "a3r_align_set_depth_prior: workspace too small (%zu < %zu)", workspace_bytes, need);
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "a3r_align_set_depth_prior: workspace must be 16-byte aligned");
+    d.prior_w = weight; d.prior_init = init_log_depth; d.prior_dyn = dynamic_mask;
+    d.gprior = static_cast<float*>(workspace);
+    d.lossP = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)d.N * d.P * 4, 256));
+    (void)stream;
+    return A3R_OK;
+}
+
 // the ego-flow pass of one iteration (before the main kernel): unscaled sums, then the normalisers / drop decision
 static void launch_flow(a3r_align_s* a, int epoch, hipStream_t st) {
     AlignDev& d = a->d;
+    if (d.prior_w > 0.f) hipLaunchKernelGGL(align_depth_prior_kernel, dim3(d.N), dim3(PRIOR_TPB), 0, st, d);
     d.flow_on = (d.flow_w > 0.f && epoch >= a->flow_start_iter) ? 1 : 0;
     if (!d.flow_on) return;
     ProfScope prof(PK_ALIGN_SMALL, 0.0, st);

@@ -8,7 +8,8 @@ temporal smoothing of consecutive camera poses, ego-flow smooth-L1 loss against 
 The optical-flow fields are INPUTS of the path: the reference computes them with RAFT inside the constructor
 (optimizer.py:118-154; SURVEY row N4, not built), here they are passed as ``flow=(flow_ij, flow_ji)``
 ([E,2,H,W] each); the dynamic masks come from ``view['dynamic_mask']`` exactly as in the reference
-(cloud_opt_flow/base_opt.py:129-138).  depth_regularize_weight > 0, use_self_mask and sam2_mask_refine raise.
+(cloud_opt_flow/base_opt.py:129-138).  depth_regularize_weight > 0 adds the scale-invariant log-depth prior towards the
+depth maps captured by _set_init_depthmap (init='mst' captures them, as in the reference).  sam2_mask_refine raises.
 """
 from __future__ import annotations
 
@@ -24,8 +25,6 @@ class PointCloudOptimizer(_Base):
                  temporal_smoothing_weight=0, translation_weight=0.1, flow_loss_start_epoch=0.15, flow_loss_thre=50,
                  sintel_ckpt=False, use_self_mask=False, pxl_thre=50, sam2_mask_refine=False, motion_mask_thre=0.35,
                  flow=None, thr_for_init_conf=False, empty_cache=False, **kwargs):
-        if depth_regularize_weight > 0:
-            raise NotImplementedError('depth_regularize_weight > 0 (depth_regularization_si_weighted) is not built')
         if flow_loss_fn != 'smooth_l1':
             raise NotImplementedError("only flow_loss_fn='smooth_l1' (the reference's 'mse' branch is broken: optimizer.py:101)")
         if sam2_mask_refine:
@@ -36,6 +35,7 @@ class PointCloudOptimizer(_Base):
         self.temporal_smoothing_weight = temporal_smoothing_weight
         self.translation_weight = translation_weight
         self.flow_loss_weight = flow_loss_weight
+        self.depth_regularize_weight = depth_regularize_weight
         self.flow_loss_start_epoch = flow_loss_start_epoch
         self.flow_loss_thre = flow_loss_thre
         self.pxl_thre = pxl_thre
@@ -140,7 +140,29 @@ class PointCloudOptimizer(_Base):
     def flow_loss_flag(self):
         return self._need_engine().flow_dropped
 
+    def _set_init_depthmap(self):
+        """optimizer.py:452-454: remember the current depth maps; the depth prior (depth_regularize_weight) pulls towards them."""
+        e = self._need_engine()
+        self.init_depthmap = [dm.detach().clone() for dm in e.params['depth'].exp()]
+        if self.depth_regularize_weight > 0:
+            if self.dynamic_masks is None:
+                raise RuntimeError("depth_regularize_weight > 0 needs view['dynamic_mask'] (the reference fails on "
+                                   "torch.stack(None), optimizer.py:549)")
+            e.set_depth_prior(float(self.depth_regularize_weight), dyn=torch.stack(self.dynamic_masks))
+
+    def get_init_depthmaps(self, raw=False):
+        res = self.init_depthmap
+        if not raw:
+            res = [dm[:h * w].view(h, w) for dm, (h, w) in zip(res, self.imshapes)]
+        return res
+
+    def _check_depth_prior(self):
+        if self.depth_regularize_weight > 0 and self._need_engine().prior is None:     # optimizer.py:547 reads self.init_depthmap
+            raise AttributeError("'PointCloudOptimizer' object has no attribute 'init_depthmap' (depth_regularize_weight > 0 "
+                                 "needs _set_init_depthmap(); init='mst' with more than 2 images calls it)")
+
     def forward(self, epoch=9999):
+        self._check_depth_prior()
         loss, _ = self._need_engine().loss_grad(epoch)
         return torch.tensor(loss, device=self.device)
 
@@ -159,6 +181,8 @@ class PointCloudOptimizer(_Base):
         elif init in ('msp', 'mst'):
             from ..cloud_opt.init_im_poses import init_minimum_spanning_tree       # parity unpinned (see that module)
             init_minimum_spanning_tree(self, init_priors=init_priors, niter_PnP=niter_PnP)
+            if self.n_imgs > 2:
+                self._set_init_depthmap()                                          # cloud_opt_flow/init_im_poses.py:149-150
         elif init == 'known_poses':
             raise NotImplementedError("init='known_poses': the reference's own branch cannot run (base_opt.py:468 hands preset_pose a "
                                       "python list, optimizer.py:325 takes .shape of it); preset_pose + init='mst' is the working route")
@@ -166,6 +190,7 @@ class PointCloudOptimizer(_Base):
             raise ValueError(f'bad value for {init=}')
         if niter <= 0:
             return float('inf')
+        self._check_depth_prior()
         e.set_params(reset_optimizer=True)
         losses = e.run(niter, lr, schedule, lr_min)
         if self.verbose:

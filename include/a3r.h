@@ -326,6 +326,15 @@ typedef struct {
 } a3r_align_flow_desc;
 size_t a3r_align_flow_workspace_bytes(int E, int N, int P);
 int a3r_align_set_flow(a3r_align_t a, const a3r_align_flow_desc* f, void* stream);
+/* Depth prior of the flow variant: depth_regularize_weight * depth_regularization_si_weighted(depthmaps, init_depthmaps,
+ * dynamic_masks) (dust3r/utils/goem_opt.py:15-36 as called at dust3r/cloud_opt_flow/optimizer.py:546-555): a scale-invariant
+ * squared log-depth distance to the depth maps captured by _set_init_depthmap (optimizer.py:452-454), pixels of the dynamic
+ * mask weighted 2, others 1, averaged over images.  init_log_depth: [N, P] log-depth parameters at capture time, device;
+ * dynamic_mask: [N, P] (1 = dynamic) or NULL; both stay owned by the caller and must outlive the handle.  weight == 0 turns
+ * the term off (other arguments ignored).  Loss, gradient export and step all include the term afterwards. */
+size_t a3r_align_depth_prior_workspace_bytes(int N, int P);
+int a3r_align_set_depth_prior(a3r_align_t a, float weight, const float* init_log_depth, const uint8_t* dynamic_mask,
+                              void* workspace, size_t workspace_bytes, void* stream);
 /* a3r_align_step with an explicit epoch (net(epoch=cur_iter), cloud_opt_flow/base_opt.py:571); a3r_align_step uses
  * the handle's own iteration count. */
 int a3r_align_step_epoch(a3r_align_t a, float lr, int epoch, void* stream);

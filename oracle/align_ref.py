@@ -111,6 +111,35 @@ class AlignOracle:
             self.flow["flow_ji"] = np.ascontiguousarray(flow["flow_ji"], np.float32).reshape(E, 2, P)
             self.flow["dyn"] = np.ascontiguousarray(flow["dyn"]).reshape(N, P).astype(np.uint8)
         self.hw = imshapes[0]
+        self.prior = None
+
+    def set_depth_prior(self, weight, dyn=None, init=None):
+        """depth_regularize_weight * depth_regularization_si_weighted(depth, init_depth, dynamic_masks)
+        (goem_opt.py:15-36 as called at cloud_opt_flow/optimizer.py:546-555)."""
+        self.prior = None if weight <= 0 else dict(
+            weight=float(weight),
+            init=np.ascontiguousarray(self.params["depth"] if init is None else init, np.float32).reshape(self.N, self.P).copy(),
+            dyn=None if dyn is None else np.ascontiguousarray(dyn).reshape(self.N, self.P).astype(bool))
+
+    def _depth_prior(self, raw):
+        """(loss, d loss / d log-depth parameter) of the prior; float64 restatement of goem_opt.py:15-36 with pixel weight
+        1 + dynamic_mask, no weight normalisation, eps = 1e-6."""
+        pr = self.prior
+        eps = 1e-6
+        loss = 0.0
+        grad = np.zeros((self.N, self.P), np.float64)
+        for n in range(self.N):
+            a = int(self.imarea[n])
+            d = np.exp(raw[n, :a].astype(np.float32)).astype(np.float64)
+            d0 = np.exp(pr["init"][n, :a]).astype(np.float64)
+            l, l0 = np.log(np.maximum(d, eps)), np.log(np.maximum(d0, eps))
+            w = 1.0 + (pr["dyn"][n, :a] if pr["dyn"] is not None else 0.0)
+            scale = np.sum(l0 - l) / a
+            r = l - l0 + scale
+            loss += np.sum(w * r * r) / a
+            gl = (2.0 / a) * (w * r - np.sum(w * r) / a)
+            grad[n, :a] = np.where(d > eps, gl, 0.0)
+        return loss / self.N, grad / self.N
 
     def set_params(self, pw_poses, depth, im_poses, im_focals, shifts=None, im_pp=None, pw_adaptors=None):
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).copy()
@@ -184,6 +213,10 @@ class AlignOracle:
                 lib().a3r_oracle_flow_loss_grad(*args, scale, sums, _p(gd), _p(g_poses), _p(g_fv), _p(g_ppv))
                 g_focals_full += g_fv * fvals / self.cfg.focal_break
                 g_pp += 10 * g_ppv
+        if self.prior is not None:
+            lp, gp = self._depth_prior(p["depth"])
+            total += self.prior["weight"] * lp
+            g["depth"] += (self.prior["weight"] * gp).astype(np.float32)
         if "im_focals" in g:
             g["im_focals"][:] = g_focals_full.sum() if self.shared_focal else g_focals_full
         return total, g

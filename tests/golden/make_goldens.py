@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only -- /root/reference does not exist on the GPU box):
-    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow|prep|hier|flowgeo] [--out tests/golden]
+    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow|alignprior|prep|hier|flowgeo] [--out tests/golden]
 
 What it does
   * puts /root/reference on sys.path (read-only, bytecode writing disabled) and imports the
@@ -519,6 +519,99 @@ def gen_alignflow(out):
         print("alignflow", tag, g[f"{tag}_loss_on"], g[f"{tag}_loss_off"], "->", losses[-1], "dropped:", net.flow_loss_flag)
     np.savez_compressed(os.path.join(out, "alignflow.npz"), **g)
     with open(os.path.join(out, "alignflow.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def gen_alignprior(out):
+    """cloud_opt_flow.PointCloudOptimizer with depth_regularize_weight > 0 (optimizer.py:546-555 ->
+    goem_opt.depth_regularization_si_weighted): the scale-invariant log-depth prior towards the depth maps captured by
+    _set_init_depthmap, dynamic pixels weighted 2.  Same scene / injection scheme as gen_alignflow."""
+    from dust3r.cloud_opt_flow import global_aligner, GlobalAlignerMode
+    from dust3r.cloud_opt_flow.base_opt import global_alignment_iter
+    import contextlib, io
+    g, meta = {}, dict(cases=[])
+    cases = [  # tag, N, H, W, shared_focal, tsw, flow_w, depth_w, schedule, lr
+        ("prior_only", 4, 16, 24, False, 0.0, 0.0, 50.0, "cosine", 0.01),
+        ("prior_flow_smooth", 5, 24, 32, True, 0.01, 0.01, 5.0, "linear", 0.01),
+    ]
+    for tag, N, H, W, shared, tsw, fw, dw, sched, lr in cases:
+        sc = _flow_scene(N, H, W, seed=5)
+        edges = sc["edges"]; E = len(edges)
+        view1 = dict(idx=[i for i, j in edges], true_shape=torch.tensor([[H, W]] * E),
+                     dynamic_mask=[torch.from_numpy(sc["dyn"][i]) for i, j in edges])
+        view2 = dict(idx=[j for i, j in edges], true_shape=torch.tensor([[H, W]] * E),
+                     dynamic_mask=[torch.from_numpy(sc["dyn"][j]) for i, j in edges])
+        pred1 = dict(pts3d=torch.from_numpy(sc["p1"]), conf=torch.from_numpy(sc["c1"]))
+        pred2 = dict(pts3d_in_other_view=torch.from_numpy(sc["p2"]), conf=torch.from_numpy(sc["c2"]))
+        torch.manual_seed(17)
+        niter = 30
+        net = global_aligner(dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2), "cpu", mode=GlobalAlignerMode.PointCloudOptimizer,
+                             verbose=False, min_conf_thr=3, shared_focal=shared, temporal_smoothing_weight=tsw, translation_weight=1.0,
+                             flow_loss_weight=0.0, depth_regularize_weight=dw, flow_loss_start_epoch=0.1, flow_loss_thre=20.0,
+                             num_total_iter=niter, pxl_thre=50)
+        net.flow_loss_weight = fw
+        net.flow_ij = torch.from_numpy(sc["flow_ij"]); net.flow_ji = torch.from_numpy(sc["flow_ji"])
+        with torch.no_grad():
+            for n in range(N):
+                R, t = sc["cams"][n]
+                a = np.arctan2(R[0, 2], R[0, 0]) + 0.01 * np.sin(n + 1.0)
+                net.im_poses[n, 0:4] = torch.tensor([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)])
+                tt = torch.tensor(t + 0.01 * np.cos(np.arange(3) + n), dtype=torch.float32)
+                net.im_poses[n, 4:7] = torch.sign(tt) * torch.log1p(tt.abs())
+                net.im_depthmaps[n] = torch.from_numpy(np.log(sc["depths"][n]).reshape(-1)).float()
+            net.im_focals[:] = float(net.focal_break * np.log(sc["f"] * 1.02))
+            net._set_init_depthmap()                              # what init='mst' does (cloud_opt_flow/init_im_poses.py:149-150)
+            g[f"{tag}_prior_init"] = net.im_depthmaps.detach().numpy().copy()
+            for n in range(N):                                    # move away from the captured maps: scale + a ripple
+                net.im_depthmaps[n] += 0.1 * (n + 1) + 0.05 * torch.sin(torch.arange(H * W) / (5.0 + n))
+        for k in ("p1", "p2", "c1", "c2", "flow_ij", "flow_ji", "dyn"):
+            g[f"{tag}_{k}"] = sc[k]
+        trainable = [n for n, p in net.named_parameters() if p.requires_grad]
+        for n, p in net.named_parameters():
+            if n in trainable or n in ("im_pp", "pw_adaptors"):
+                g[f"{tag}_init_{n}"] = p.detach().numpy().copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = net(epoch=9999)
+        loss.backward()
+        g[f"{tag}_loss"] = np.float64(loss.item())
+        for n, p in net.named_parameters():
+            if n in trainable:
+                g[f"{tag}_grad_{n}"] = p.grad.numpy().copy()
+                p.grad = None
+        net.depth_regularize_weight = 0.0                     # the same state without the prior: isolates the term
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss0 = net(epoch=9999)
+        loss0.backward()
+        g[f"{tag}_loss_noprior"] = np.float64(loss0.item())
+        g[f"{tag}_grad_noprior_im_depthmaps"] = net.im_depthmaps.grad.numpy().copy()
+        for p in net.parameters():
+            p.grad = None
+        net.depth_regularize_weight = dw
+        # the prior alone, straight from the reference's function
+        from dust3r.utils.goem_opt import depth_regularization_si_weighted
+        with torch.no_grad():
+            g[f"{tag}_prior_value"] = np.float64(depth_regularization_si_weighted(
+                torch.stack(net.get_depthmaps(raw=False)).unsqueeze(1), torch.stack(net.get_init_depthmaps(raw=False)).unsqueeze(1),
+                torch.stack(net.dynamic_masks).unsqueeze(1)).item())
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.9))
+        losses = []
+        for it in range(niter):
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss, _ = global_alignment_iter(net, it, niter, lr, 1e-3, opt, sched)
+            losses.append(loss)
+            if it + 1 in (1, 10, 30):
+                for n, p in net.named_parameters():
+                    if n in trainable:
+                        g[f"{tag}_k{it+1}_{n}"] = p.detach().numpy().copy()
+        g[f"{tag}_losses"] = np.asarray(losses, np.float64)
+        meta["cases"].append(dict(tag=tag, N=N, H=H, W=W, edges=edges, shared_focal=shared, temporal_smoothing_weight=tsw,
+                                  translation_weight=1.0, flow_loss_weight=fw, depth_regularize_weight=dw, flow_loss_thre=20.0,
+                                  flow_loss_start_epoch=0.1, pxl_thre=50, schedule=sched, lr=lr, lr_min=1e-3, niter=niter,
+                                  trainable=trainable, flow_dropped=bool(net.flow_loss_flag)))
+        print("alignprior", tag, g[f"{tag}_loss"], g[f"{tag}_prior_value"], "->", losses[-1], "dropped:", net.flow_loss_flag)
+    np.savez_compressed(os.path.join(out, "alignprior.npz"), **g)
+    with open(os.path.join(out, "alignprior.json"), "w") as f:
         json.dump(meta, f)
 
 

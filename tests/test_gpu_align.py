@@ -190,3 +190,55 @@ def test_flow_variant_trajectory_vs_reference(case, gf, Engine):
             assert rel_err(host(a.params[kk]).reshape(ref.shape), ref) < 1e-4, (k, kk)
     assert rel_err(np.asarray(losses), gf[tag + "_losses"]) < 1e-5
     assert a.flow_dropped == case["flow_dropped"]
+
+
+# ------------------------------------------------------------------------------------------------- depth prior of cloud_opt_flow
+from test_oracle_align import PRIOR_META, build_prior
+
+
+@pytest.fixture(scope="module")
+def gp():
+    return np.load(os.path.join(GOLDEN, "alignprior.npz"))
+
+
+@pytest.mark.parametrize("case", PRIOR_META["cases"], ids=[c["tag"] for c in PRIOR_META["cases"]])
+def test_depth_prior_gradients_vs_reference(case, gp, Engine):
+    """a3r_align_set_depth_prior: loss + gradients against the reference's autograd, and the prior in isolation."""
+    a = build_prior(case, gp, cls=Engine)
+    tag = case["tag"]
+    loss, gr = a.loss_grad(9999)
+    assert abs(loss - gp[tag + "_loss"]) / gp[tag + "_loss"] < 1e-6
+    assert abs(float(a.loss()) - gp[tag + "_loss"]) / gp[tag + "_loss"] < 1e-6          # the loss-only launch too
+    for k, v in gr.items():
+        ref = gp[f"{tag}_grad_{FLOW_NAMES[k]}"]
+        assert rel_err(host(v).reshape(ref.shape), ref) < 1e-5, k
+    full = host(gr["depth"]).astype(np.float64)
+    a.set_depth_prior(0.0)
+    loss0, gr0 = a.loss_grad(9999)
+    assert abs(loss0 - gp[tag + "_loss_noprior"]) / gp[tag + "_loss_noprior"] < 1e-6
+    ref = gp[tag + "_grad_im_depthmaps"].astype(np.float64) - gp[tag + "_grad_noprior_im_depthmaps"]
+    assert rel_err((full - host(gr0["depth"])).reshape(ref.shape), ref) < 1e-3
+
+
+@pytest.mark.parametrize("case", PRIOR_META["cases"], ids=[c["tag"] for c in PRIOR_META["cases"]])
+def test_depth_prior_trajectory_vs_reference(case, gp, Engine):
+    a = build_prior(case, gp, cls=Engine)
+    tag = case["tag"]
+    losses, done = [], 0
+    for k in (1, 10, 30):
+        losses += list(a.run(k - done, case["lr"], case["schedule"], case["lr_min"], first_iter=done, total_iters=case["niter"]))
+        done = k
+        for kk in a.trainable():
+            ref = gp[f"{tag}_k{k}_{FLOW_NAMES[kk]}"]
+            assert rel_err(host(a.params[kk]).reshape(ref.shape), ref) < 1e-4, (k, kk)
+    assert rel_err(np.asarray(losses), gp[tag + "_losses"]) < 1e-5
+
+
+def test_depth_prior_argument_errors(gp, Engine):
+    case = PRIOR_META["cases"][0]
+    a = build_flow(case, gp, cls=Engine)
+    from align3r_amd._lib import check
+    with pytest.raises(RuntimeError, match="initial depth maps are missing"):
+        check(a.lib.a3r_align_set_depth_prior(a.handle, 1.0, None, None, None, 0, None))
+    with pytest.raises(RuntimeError, match="workspace too small"):
+        check(a.lib.a3r_align_set_depth_prior(a.handle, 1.0, a.params["depth"].data_ptr(), None, a.params["depth"].data_ptr(), 16, None))

@@ -143,6 +143,40 @@ def test_cloud_opt_flow_api_vs_reference_golden(model):
         global_aligner(out, "cuda", flow_loss_weight=0.01, verbose=False)
 
 
+def test_cloud_opt_flow_depth_prior_api_vs_reference_golden(model):
+    """depth_regularize_weight > 0 through the mirror class: _set_init_depthmap captures the maps (what init='mst' does for more
+    than two images), compute_global_alignment re-creates the handle and must keep the prior; against the reference's own
+    30-iteration trajectory (tests/golden/alignprior.npz)."""
+    import json
+    from dust3r.cloud_opt_flow import global_aligner, GlobalAlignerMode
+    g = np.load(os.path.join(GOLDEN, "alignprior.npz"))
+    case = json.load(open(os.path.join(GOLDEN, "alignprior.json")))["cases"][0]
+    tag, N, H, W, edges = case["tag"], case["N"], case["H"], case["W"], case["edges"]
+    dyn = torch.from_numpy(g[tag + "_dyn"])
+    out = dict(view1=dict(idx=[i for i, j in edges], dynamic_mask=[dyn[i] for i, j in edges]),
+               view2=dict(idx=[j for i, j in edges], dynamic_mask=[dyn[j] for i, j in edges]),
+               pred1=dict(pts3d=torch.from_numpy(g[tag + "_p1"]), conf=torch.from_numpy(g[tag + "_c1"])),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(g[tag + "_p2"]), conf=torch.from_numpy(g[tag + "_c2"])))
+    kw = dict(mode=GlobalAlignerMode.PointCloudOptimizer, verbose=False, min_conf_thr=3, shared_focal=case["shared_focal"],
+              temporal_smoothing_weight=case["temporal_smoothing_weight"], translation_weight=case["translation_weight"],
+              num_total_iter=case["niter"])
+    scene = global_aligner(out, "cuda", depth_regularize_weight=case["depth_regularize_weight"], **kw)
+    with pytest.raises(AttributeError, match="init_depthmap"):           # optimizer.py:547 before _set_init_depthmap
+        scene()
+    scene.engine.set_params(depth=g[tag + "_prior_init"])
+    scene._set_init_depthmap()
+    assert rel_err(torch.stack(scene.get_init_depthmaps()).cpu().numpy().reshape(N, -1), np.exp(g[tag + "_prior_init"])) < 1e-6
+    scene.engine.set_params(pw_poses=g[tag + "_init_pw_poses"], depth=g[tag + "_init_im_depthmaps"],
+                            im_poses=g[tag + "_init_im_poses"], im_focals=g[tag + "_init_im_focals"])
+    assert abs(float(scene()) - g[tag + "_loss"]) / g[tag + "_loss"] < 1e-6
+    loss = scene.compute_global_alignment(init=None, niter=case["niter"], schedule=case["schedule"], lr=case["lr"], lr_min=case["lr_min"])
+    assert abs(loss - g[tag + "_losses"][-1]) / g[tag + "_losses"][-1] < 1e-5
+    assert rel_err(torch.stack(scene.get_depthmaps()).cpu().numpy().reshape(N, -1), np.exp(g[tag + "_k30_im_depthmaps"])) < 1e-4
+    nomask = dict(out, view1=dict(idx=out["view1"]["idx"]), view2=dict(idx=out["view2"]["idx"]))
+    with pytest.raises(RuntimeError, match="dynamic_mask"):
+        global_aligner(nomask, "cuda", depth_regularize_weight=1.0, **kw)._set_init_depthmap()
+
+
 def _geom_scene(N, H, W, seed=0):
     """Consistent synthetic scene (true depth, poses, focal) and DUSt3R-style pairwise pointmaps of its complete graph."""
     rng = np.random.default_rng(seed)

@@ -127,3 +127,54 @@ def test_flow_variant_trajectory(case, gf):
             assert rel_err(o.params[kk].reshape(ref.shape), ref) < 1e-4, (k, kk)
     assert rel_err(np.asarray(losses), gf[tag + "_losses"]) < 1e-5
     assert o.flow_dropped == case["flow_dropped"]          # flow_loss > flow_loss_thre -> term dropped (optimizer.py:538-540)
+
+
+# ------------------------------------------------------------------------------------------------- depth prior of cloud_opt_flow
+PRIOR_META = json.load(open(os.path.join(GOLDEN, "alignprior.json")))
+
+
+def build_prior(case, g, cls=AlignOracle, **kw):
+    o = build_flow(case, g, cls=cls, **kw)
+    tag = case["tag"]
+    o.set_depth_prior(case["depth_regularize_weight"], dyn=g[tag + "_dyn"], init=g[tag + "_prior_init"])
+    return o
+
+
+@pytest.fixture(scope="module")
+def gp():
+    return np.load(os.path.join(GOLDEN, "alignprior.npz"))
+
+
+@pytest.mark.parametrize("case", PRIOR_META["cases"], ids=[c["tag"] for c in PRIOR_META["cases"]])
+def test_depth_prior_loss_and_gradients(case, gp):
+    """depth_regularize_weight > 0 (optimizer.py:546-555, goem_opt.py:15-36) vs the reference's autograd; the term in isolation
+    through the same state evaluated with weight 0."""
+    o = build_prior(case, gp)
+    tag = case["tag"]
+    loss, gr = o.loss_grad(9999)
+    assert abs(loss - gp[tag + "_loss"]) / gp[tag + "_loss"] < 1e-6
+    for k, v in gr.items():
+        ref = gp[f"{tag}_grad_{FLOW_NAMES[k]}"]
+        assert rel_err(v.reshape(ref.shape), ref) < 1e-5, k
+    o.set_depth_prior(0.0)
+    loss0, gr0 = o.loss_grad(9999)
+    assert abs(loss0 - gp[tag + "_loss_noprior"]) / gp[tag + "_loss_noprior"] < 1e-6
+    w = case["depth_regularize_weight"]
+    assert abs((loss - loss0) / w - gp[tag + "_prior_value"]) / gp[tag + "_prior_value"] < 1e-3     # fp32 loss difference
+    ref = gp[tag + "_grad_im_depthmaps"].astype(np.float64) - gp[tag + "_grad_noprior_im_depthmaps"]
+    mine = gr["depth"].astype(np.float64) - gr0["depth"]
+    assert rel_err(mine.reshape(ref.shape), ref) < 1e-4
+
+
+@pytest.mark.parametrize("case", PRIOR_META["cases"], ids=[c["tag"] for c in PRIOR_META["cases"]])
+def test_depth_prior_trajectory(case, gp):
+    o = build_prior(case, gp)
+    tag = case["tag"]
+    losses, done = [], 0
+    for k in (1, 10, 30):
+        losses += o.run(k - done, case["lr"], case["schedule"], case["lr_min"], first_iter=done, total_iters=case["niter"])
+        done = k
+        for kk in o.trainable():
+            ref = gp[f"{tag}_k{k}_{FLOW_NAMES[kk]}"]
+            assert rel_err(o.params[kk].reshape(ref.shape), ref) < 1e-4, (k, kk)
+    assert rel_err(np.asarray(losses), gp[tag + "_losses"]) < 1e-5
