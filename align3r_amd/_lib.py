@@ -74,6 +74,8 @@ SIGNATURES = {
     "a3r_bf3_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "a3r_bf3_set_products": (C.c_int, [C.c_int]),
     "a3r_split_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),
+    "a3r_bf3_w_bytes": (C.c_size_t, [C.c_long, C.c_int]),
+    "a3r_split_bf3_w": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),
     "a3r_layernorm_bf3": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
     "a3r_linear_bf3": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_linear_bf3_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),

@@ -4,10 +4,21 @@
 // Memory layout of a [R, K] matrix (K % 8 == 0): [R][K/8][3][8] bf16 -- per row and per group of 8 consecutive k
 // the three planes' 16-byte pieces are adjacent (48 bytes), which is exactly one lane's A/B operand of
 // v_mfma_f32_32x32x16_bf16 per plane.  Row pitch = 6 K bytes.
+//
+// WEIGHT matrices (the B operand of gemm_bf3.hip; K % 32 == 0) use the ROW-PAIR form of the same layout,
+// [ceil(N/2)][K/32][2 rows][4 k-groups][3][8] bf16: rows 2j and 2j+1 are interleaved per 32-deep k block, so the 32 k of a row
+// pair that one GEMM stage needs are 384 contiguous bytes = three whole 128-byte cache lines.  In the plain form a stage
+// takes 192 bytes = 1.5 lines of every row, i.e. it drags 2 lines through the L2 -> LDS path for 1.5 lines of payload;
+// measured on MI355X (tools/gemm_bf3_lab.hip, "RB2"): +2-3.5 % GEMM throughput from the weights alone, +4.5-5.5 % if the A
+// operand is stored the same way (not done: activations are produced and sliced by row in many kernels).
+//   byte offset of (row n, k) = (n / 2) * 12 K + (k / 32) * 384 + (n % 2) * 192 + ((k / 8) % 4) * 48 [+ plane * 16 + (k % 8) * 2]
 #pragma once
 #include "common.h"
 
 namespace a3r {
+
+__host__ __device__ inline size_t bf3_w_row_offset(int n, int K) { return (size_t)(n >> 1) * ((size_t)12 * K) + (size_t)(n & 1) * 192; }
+constexpr int BF3_W_KBLOCK_BYTES = 384;      // one 32-deep k block of a weight row pair
 
 int bf3_products();        // 6 | 3 | 1: the process-wide product set of the bf3 kernels (gemm_bf3.hip)
 

@@ -53,6 +53,7 @@ template <int AMODE, int BM, int BN, int BK, int WM, int WN, int NS, int MF, boo
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     constexpr bool M16 = MF == 16;
     static_assert(MF == 32 || (MF == 16 && BK == 32), "16x16x32 MFMA needs BK = 32");
+    static_assert(BK == 32, "the row-pair weight layout is addressed in 32-deep k blocks");
     constexpr int NT = WM * WN * 64, KG = BK / 8, U = 3 * KG, G = KG, PER = 16 / G;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int SA = BM * U, SB = BN * U;                                 // 16-byte units per stage
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     for (int i = 0; i < LB; i++) {
         const int slot = tid + NT * i, r = (slot / U) % BN, cp = slot % U;
         const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
-        srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + src_unit(r, cp) * 16;
+        srcB[i] = reinterpret_cast<const char*>(P.Wt) + bf3_w_row_offset(gn, g.K) + src_unit(r, cp) * 16;     // row-pair weight layout (bf3.h)
     }
     const bool lastA = (LA - 1) * NT + wave * 64 < SA, lastB = (LB - 1) * NT + wave * 64 < SB;   // wave-uniform
     const int lps = LA + LB - ((SA % NT != 0 && !lastA) ? 1 : 0) - ((SB % NT != 0 && !lastB) ? 1 : 0);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < LB; i++)
             if (i + 1 < LB || SB % NT == 0 || lastB)
-                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + (size_t)kt * BF3_W_KBLOCK_BYTES), (lptr_t)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
     };
     // Stage kt is consumed after (a) this wave's DMAs for it have landed -- a counted vmcnt that leaves the younger stages in
     // flight -- and (b) the barrier, which extends (a) to the workgroup and also says every wave is done with stage kt-1,
@@ -295,10 +296,10 @@ __global__ __launch_bounds__(512) void gemm_bf3_w2h_kernel(GemmArgs g) {
         for (int i = 0; i < LH; i++) {
             const int slot = tid + NT * i, r = slot / U, cp = slot % U;
             const int rr = FULL ? h * HN + r : min(n0 + h * HN + r, g.N - 1) - n0;
-            offW[h][i] = (unsigned)(rr * pitch) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;
+            offW[h][i] = (unsigned)bf3_w_row_offset(rr, g.K) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;      // relative to row n0 (even)
         }
     const char* Abase = reinterpret_cast<const char*>(P.A) + (size_t)m0 * pitch;
-    const char* Wbase = reinterpret_cast<const char*>(P.Wt) + (size_t)n0 * pitch;
+    const char* Wbase = reinterpret_cast<const char*>(P.Wt) + bf3_w_row_offset(n0, g.K);            // n0 is a multiple of 256
     auto issue_a = [&](int kt, int buf) {
         char* base = As + buf * A_BYTES + wave * 1024;
         const char* src = Abase + (size_t)kt * 192;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(512) void gemm_bf3_w2h_kernel(GemmArgs g) {
     };
     auto issue_w = [&](int kt, int half) {
         char* base = Hs + half * H_BYTES + wave * 1024;
-        const char* src = Wbase + (size_t)kt * 192;
+        const char* src = Wbase + (size_t)kt * BF3_W_KBLOCK_BYTES;
 #pragma unroll
         for (int i = 0; i < LH; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + offW[half][i]), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
     };
@@ -379,13 +380,16 @@ __global__ __launch_bounds__(512) void gemm_bf3_w2h_kernel(GemmArgs g) {
 }
 
 // fp32 [M, ldx] -> bf3 [M][K/8][3][8]: one thread per group of 8 consecutive k (32 B in, 48 contiguous bytes out)
+// WPAIR: the row-pair weight layout of bf3.h (K % 32 == 0)
+template <bool WPAIR>
 __global__ __launch_bounds__(256) void split_bf3_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8) {
     const long total = M * K8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long row = i / K8;
         const int kg = (int)(i - row * K8);
         const f32x4* src = reinterpret_cast<const f32x4*>(x + row * ldx + kg * 8);
-        bf3_store8(y + row * ((size_t)K8 * 48), kg * 8, src[0], src[1]);
+        if (WPAIR) bf3_store8(y + bf3_w_row_offset((int)row, K8 * 8) + (size_t)(kg >> 2) * BF3_W_KBLOCK_BYTES, (kg & 3) * 8, src[0], src[1]);
+        else bf3_store8(y + row * ((size_t)K8 * 48), kg * 8, src[0], src[1]);
     }
 }
 
@@ -487,19 +491,32 @@ extern "C" int a3r_bf3_set_products(int products) {
 
 extern "C" size_t a3r_bf3_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)rows * K * 6 : 0; }
 
-extern "C" int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream) {
-    A3R_CHECK_ARG(x && y, "a3r_split_bf3: null pointer");
-    A3R_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0, "a3r_split_bf3: K (%d) must be a positive multiple of 8 (M=%ld)", K, M);
-    A3R_CHECK_ARG(ldx >= K && ldx % 4 == 0, "a3r_split_bf3: bad leading dimension %d", ldx);
-    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "a3r_split_bf3: pointers must be 16-byte aligned");
+static int split_bf3_impl(const float* x, int ldx, void* y, long M, int K, bool wpair, void* stream) {
+    const char* who = wpair ? "a3r_split_bf3_w" : "a3r_split_bf3";
+    A3R_CHECK_ARG(x && y, "%s: null pointer", who);
+    A3R_CHECK_ARG(M > 0 && K > 0 && K % (wpair ? 32 : 8) == 0, "%s: K (%d) must be a positive multiple of %d (M=%ld)", who, K, wpair ? 32 : 8, M);
+    A3R_CHECK_ARG(!wpair || M < (1L << 31), "%s: too many rows", who);
+    A3R_CHECK_ARG(ldx >= K && ldx % 4 == 0, "%s: bad leading dimension %d", who, ldx);
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
     const long total = M * (K / 8);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PK_SPLIT, 10.0 * M * K, st);
     const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(split_bf3_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, st, x, ldx,
-                       static_cast<char*>(y), M, K / 8);
+    const dim3 grid((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4));
+    if (wpair) hipLaunchKernelGGL(split_bf3_kernel<true>, grid, dim3(256), 0, st, x, ldx, static_cast<char*>(y), M, K / 8);
+    else hipLaunchKernelGGL(split_bf3_kernel<false>, grid, dim3(256), 0, st, x, ldx, static_cast<char*>(y), M, K / 8);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
+}
+
+extern "C" int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream) {
+    return split_bf3_impl(x, ldx, y, M, K, false, stream);
+}
+
+// weights [N, K] -> the row-pair weight layout (bf3.h); y holds a3r_bf3_w_bytes(N, K) bytes (an odd N leaves the last pair half empty)
+extern "C" size_t a3r_bf3_w_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)((rows + 1) / 2 * 2) * K * 6 : 0; }
+extern "C" int a3r_split_bf3_w(const float* w, int ldw, void* y, long N, int K, void* stream) {
+    return split_bf3_impl(w, ldw, y, N, K, true, stream);
 }
 
 extern "C" int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int ldc, int M, int N, int K,

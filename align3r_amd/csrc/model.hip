@@ -152,7 +152,7 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
     if (m->use_bf3) {
         auto twin = [&](const std::string& n, int N, int K) {
             v.push_back({n, 4, N, K, 0, off});
-            off = align_up(off + (size_t)N * K * 6, 256);
+            off = align_up(off + a3r_bf3_w_bytes(N, K), 256);
         };
         auto block = [&](const std::string& p, int Dm, bool cross) {
             twin(p + ".attn.qkv.weight", 3 * Dm, Dm); twin(p + ".attn.proj.weight", Dm, Dm);
@@ -346,7 +346,7 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
         if (pit != packed_ptr.end()) src = pit->second;                 // the concatenated cross-attention k/v projection
         else src = m->w.at(it.name).p;                                   // bound (and shape-checked) above
         void* dst = pk + it.off;
-        if (int rc = a3r_split_bf3(src, it.b, dst, it.a, it.b, stream)) return rc;
+        if (int rc = a3r_split_bf3_w(src, it.b, dst, it.a, it.b, stream)) return rc;     // weights: row-pair layout (bf3.h)
         m->w3[src] = dst;
     }
     m->finalized = true;

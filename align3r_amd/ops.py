@@ -124,15 +124,19 @@ def bf3_set_products(n: int) -> int:
 class Bf3:
     """An fp32 matrix [rows, K] in bf3 form (three exact bf16 planes, include/a3r.h): uint8 storage + logical shape."""
 
-    def __init__(self, data: torch.Tensor, rows: int, K: int):
-        self.data, self.rows, self.K = data, rows, K
+    def __init__(self, data: torch.Tensor, rows: int, K: int, weight: bool = False):
+        self.data, self.rows, self.K, self.weight = data, rows, K, weight          # weight: the row-pair weight layout
 
     def data_ptr(self):
         return self.data.data_ptr()
 
     def planes(self):
         """-> float32 [3, rows, K]: the three planes (their sum is the original matrix exactly)."""
-        u = self.data.view(torch.int16).view(self.rows, self.K // 8, 3, 8).to(torch.int32) << 16
+        if self.weight:        # [ceil(rows/2)][K/32][2][4][3][8] -> rows-major
+            u = self.data.view(torch.int16).view(-1, self.K // 32, 2, 4, 3, 8).permute(0, 2, 1, 3, 4, 5)
+            u = u.reshape(-1, self.K // 8, 3, 8)[:self.rows].to(torch.int32) << 16
+        else:
+            u = self.data.view(torch.int16).view(self.rows, self.K // 8, 3, 8).to(torch.int32) << 16
         return u.view(torch.float32).permute(2, 0, 1, 3).reshape(3, self.rows, self.K)
 
 
@@ -144,6 +148,21 @@ def split_bf3(x) -> Bf3:
     y = torch.empty(M * K * 6, device=x.device, dtype=torch.uint8)
     check(_lib.load().a3r_split_bf3(ptr(x), K, ptr(y), M, K, stream_ptr()), "split_bf3")
     return Bf3(y, M, K)
+
+
+def split_bf3_w(w) -> Bf3:
+    """fp32 weights [N, K] -> bf3 in the row-pair weight layout (a3r_split_bf3_w): the w3 / wp3 operand of linear_bf3 / conv3x3_bf3."""
+    _req(w, "w")
+    N, K = w.shape
+    lib = _lib.load()
+    y = torch.zeros(int(lib.a3r_bf3_w_bytes(N, K)), device=w.device, dtype=torch.uint8)
+    check(lib.a3r_split_bf3_w(ptr(w), K, ptr(y), N, K, stream_ptr()), "split_bf3_w")
+    return Bf3(y, N, K, weight=True)
+
+
+def _need_weight_layout(w3, who):
+    if not w3.weight:
+        raise RuntimeError(f"{who}: the weight operand must be in the row-pair weight layout (ops.split_bf3_w)")
 
 
 def layernorm_bf3(x, w, b, eps=1e-6) -> Bf3:
@@ -159,6 +178,7 @@ def layernorm_bf3(x, w, b, eps=1e-6) -> Bf3:
 def linear_bf3(x3: Bf3, w3: Bf3, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
     """nn.Linear on the bf16 matrix cores with fp32 accuracy: x3 [M, K], w3 [N, K] in bf3 form (a3r_linear_bf3)."""
     M, K, N = x3.rows, x3.K, w3.rows
+    _need_weight_layout(w3, "linear_bf3")
     if w3.K != K:
         raise RuntimeError(f"linear_bf3: K mismatch ({K} vs {w3.K})")
     e = make_epilogue(epi, bias, **kw)
@@ -177,6 +197,8 @@ def linear_bf3_grouped(x3s, w3s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
     """Several same-shape bf3 nn.Linear problems in one launch (a3r_linear_bf3_grouped)."""
     G = len(x3s)
     M, K, N = x3s[0].rows, x3s[0].K, w3s[0].rows
+    for w3 in w3s:
+        _need_weight_layout(w3, "linear_bf3_grouped")
     outs = [torch.empty((M, N), device=x3s[0].data.device, dtype=torch.float32) for _ in range(G)]
     arr = (_lib.GroupPtrs * G)()          # same field layout as a3r_group_ptrs_bf3
     for i in range(G):
@@ -193,6 +215,7 @@ def conv3x3_bf3(x3: Bf3, wp3: Bf3, shape, bias=None, stride=1, epi=_lib.EPI_NONE
     packed weights [Cout, 9 Cin].  Returns fp32 [B, Ho, Wo, Cout] (or a Bf3 with out_bf3=True)."""
     B, H, W, Cin = shape
     Cout = wp3.rows
+    _need_weight_layout(wp3, "conv3x3_bf3")
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     e = make_epilogue(epi, bias, **kw)
     if e.out_bf3:

@@ -135,14 +135,21 @@ size_t a3r_bf3_bytes(long rows, int K);
 int a3r_bf3_set_products(int products);
 /* fp32 x [M, ldx] (first K columns) -> bf3 y [M][K/8][3][8] */
 int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream);
+/* WEIGHT operands (w3 of a3r_linear_bf3, wp3 of a3r_conv3x3_bf3) use the row-pair form of the layout,
+ * [ceil(N/2)][K/32][2 rows][4][3][8] bf16 (K % 32 == 0): rows 2j, 2j+1 interleaved per 32-deep k block, so the 32 k of a row
+ * pair that one GEMM stage fetches are 384 contiguous bytes = three whole cache lines (the plain form drags 2 lines per row for
+ * 1.5 lines of payload).  byte offset of (n, k) = (n/2) 12K + (k/32) 384 + (n%2) 192 + ((k/8)%4) 48 + plane 16 + (k%8) 2. */
+size_t a3r_bf3_w_bytes(long rows, int K);
+int a3r_split_bf3_w(const float* w, int ldw, void* y, long N, int K, void* stream);
 /* nn.LayerNorm (as a3r_layernorm) writing its output directly in bf3 form (D % 8 == 0): the producer of every
  * transformer GEMM input (blocks.py:127-130,186-190), fused so the fp32 normalised rows never reach HBM. */
 int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps, void* stream);
+/* x3: bf3 [M, K] (a3r_split_bf3 / a3r_layernorm_bf3 / a bf3 epilogue output); w3: [N, K] in the weight layout (a3r_split_bf3_w) */
 int a3r_linear_bf3(const void* x3, const void* w3, float* y, int ldc, int M, int N, int K, const a3r_epilogue* epi,
                    void* stream);
 typedef struct {
     const void* x3;       /* bf3 [M, K] */
-    const void* w3;       /* bf3 [N, K] */
+    const void* w3;       /* bf3 [N, K], row-pair weight layout (a3r_split_bf3_w) */
     float* y;
     const float* bias;
     const float* resid;
@@ -153,7 +160,7 @@ int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int l
 
 /* nn.Conv2d(k=3, padding=1, stride in {1,2}) as an implicit GEMM on the bf3 kernel: x3 = bf3 form of the channels-last map
  * [B, H, W, Cin] (i.e. of the [B H W, Cin] matrix), wp3 = bf3 form of the packed weights [Cout, 9 Cin] (a3r_pack_conv3x3
- * then a3r_split_bf3); y [B, Ho, Wo, Cout] fp32 (or bf3 with out_bf3).  Same call sites as a3r_conv3x3 (dpt_block.py). */
+ * then a3r_split_bf3_w); y [B, Ho, Wo, Cout] fp32 (or bf3 with out_bf3).  Same call sites as a3r_conv3x3 (dpt_block.py). */
 int a3r_conv3x3_bf3(const void* x3, const void* wp3, float* y, int B, int H, int W, int Cin, int Cout, int stride,
                     const a3r_epilogue* epi, void* stream);
 

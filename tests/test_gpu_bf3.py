@@ -54,12 +54,12 @@ def test_layernorm_bf3_equals_layernorm_then_split(ops, M, D):
 
 
 @pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
-@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1000, 384, 128), (768, 1024, 1024), (130, 64, 32)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1000, 384, 128), (768, 1024, 1024), (130, 64, 32), (130, 201, 64)])
 def test_linear_bf3_every_tile_shape(ops, monkeypatch, tile, M, N, K):
     from align3r_amd import _lib
     monkeypatch.setenv("A3R_BF3_TILE", tile)
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
-    x3, w3 = ops.split_bf3(x), ops.split_bf3(w)
+    x3, w3 = ops.split_bf3(x), ops.split_bf3_w(w)
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     assert rel_err(cpu(ops.linear_bf3(x3, w3, b)), cpu(ref)) < TOL
     assert rel_err(cpu(ops.linear_bf3(x3, w3, b, epi=_lib.EPI_GELU)), cpu(torch.nn.functional.gelu(ref))) < TOL
@@ -78,7 +78,7 @@ def test_linear_bf3_output_in_bf3_form(ops, monkeypatch, tile, M, N, K):
     """fc1 + GELU writing the next GEMM's input directly == the fp32 result split afterwards, bit for bit."""
     from align3r_amd import _lib
     monkeypatch.setenv("A3R_BF3_TILE", tile)
-    x3, w3, b = ops.split_bf3(rnd(M, K, seed=1)), ops.split_bf3(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
+    x3, w3, b = ops.split_bf3(rnd(M, K, seed=1)), ops.split_bf3_w(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
     for epi in (_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_RELU):
         y3 = ops.linear_bf3(x3, w3, b, epi=epi, out_bf3=True)
         want = ops.split_bf3(ops.linear_bf3(x3, w3, b, epi=epi))
@@ -95,7 +95,7 @@ def test_linear_bf3_error_not_larger_than_fp32_mfma(ops):
     x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     ref = x.double() @ w.double().T
     mag = x.double().abs() @ w.double().abs().T
-    e_bf3 = float(((ops.linear_bf3(ops.split_bf3(x), ops.split_bf3(w)).double() - ref).abs() / mag).max())
+    e_bf3 = float(((ops.linear_bf3(ops.split_bf3(x), ops.split_bf3_w(w)).double() - ref).abs() / mag).max())
     e_f32 = float(((ops.linear(x, w).double() - ref).abs() / mag).max())
     assert e_bf3 < 4e-7
     assert e_bf3 <= 1.5 * e_f32 + 1e-8, (e_bf3, e_f32)
@@ -108,7 +108,7 @@ def test_linear_bf3_grouped_and_determinism(ops):
     ws = [rnd(N, K, seed=10 + i, scale=K ** -0.5) for i in range(2)]
     bs = [rnd(N, seed=20 + i) for i in range(2)]
     rs = [rnd(M, N, seed=30 + i) for i in range(2)]
-    x3s, w3s = [ops.split_bf3(x) for x in xs], [ops.split_bf3(w) for w in ws]
+    x3s, w3s = [ops.split_bf3(x) for x in xs], [ops.split_bf3_w(w) for w in ws]
     outs = ops.linear_bf3_grouped(x3s, w3s, bs, epi=_lib.EPI_RESID, resids=rs)
     again = ops.linear_bf3_grouped(x3s, w3s, bs, epi=_lib.EPI_RESID, resids=rs)
     for i in range(2):
@@ -118,13 +118,29 @@ def test_linear_bf3_grouped_and_determinism(ops):
 
 
 def test_linear_bf3_argument_checks(ops):
-    x3, w3 = ops.split_bf3(rnd(64, 48, seed=1)), ops.split_bf3(rnd(64, 48, seed=2))
+    x3 = ops.split_bf3(rnd(64, 48, seed=1))
+    w3 = ops.Bf3(torch.zeros(64 * 48 * 6, dtype=torch.uint8, device="cuda"), 64, 48, weight=True)
     with pytest.raises(RuntimeError, match="multiple of 32"):
         ops.linear_bf3(x3, w3)
     with pytest.raises(RuntimeError, match="K mismatch"):
         ops.linear_bf3(ops.split_bf3(rnd(64, 64, seed=1)), w3)
     with pytest.raises(RuntimeError, match="multiple of 8"):
         ops.split_bf3(rnd(4, 12, seed=1))
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.split_bf3_w(rnd(4, 48, seed=1))
+    with pytest.raises(RuntimeError, match="weight layout"):          # a plain bf3 matrix is not a valid weight operand
+        ops.linear_bf3(ops.split_bf3(rnd(64, 64, seed=1)), ops.split_bf3(rnd(64, 64, seed=2)))
+
+
+@pytest.mark.parametrize("N,K", [(7, 64), (768, 768), (4096, 1024), (2, 32)])
+def test_weight_layout_split_is_exact(ops, N, K):
+    """a3r_split_bf3_w: the row-pair weight layout holds the same three planes as the plain form (odd N: half-empty last pair)."""
+    w = rnd(N, K, seed=5, scale=0.7)
+    w3 = ops.split_bf3_w(w)
+    assert w3.data.numel() == (N + 1) // 2 * 2 * K * 6
+    assert torch.equal(w3.planes(), ops.split_bf3(w).planes())
+    p = w3.planes()
+    assert torch.equal((p[0] + p[1]) + p[2], w)
 
 
 @pytest.mark.parametrize("tile", ["0", "1", "2"])
@@ -138,7 +154,7 @@ def test_conv3x3_bf3_vs_float64(ops, monkeypatch, tile, B, H, W, Cin, Cout, stri
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=3)
     x3 = ops.split_bf3(x)
-    wp3 = ops.split_bf3(ops.pack_conv3x3(w).reshape(Cout, 9 * Cin))
+    wp3 = ops.split_bf3_w(ops.pack_conv3x3(w).reshape(Cout, 9 * Cin))
     ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
     y = ops.conv3x3_bf3(x3, wp3, (B, H, W, Cin), b, stride=stride)
     assert rel_err(cpu(y), cpu(ref)) < TOL
@@ -176,7 +192,7 @@ def test_reduced_product_modes(ops):
     float64 relative to sum|x||w|: 6 -> fp32 level, 3 -> ~1e-6, 1 -> bf16 level; the mode is restored afterwards."""
     M, N, K = 512, 384, 1024
     x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
-    x3, w3 = ops.split_bf3(x), ops.split_bf3(w)
+    x3, w3 = ops.split_bf3(x), ops.split_bf3_w(w)
     ref = x.double() @ w.double().T
     mag = x.double().abs() @ w.double().abs().T
     err = {}

@@ -38,7 +38,7 @@ def main():
     print(f"{'shape':18s} {'M':>7s} {'N':>5s} {'K':>5s} g " + " ".join(f"{'tile ' + t:>22s}" for t in tiles))
     for name, M, N, K, G, cnt in SHAPES:
         xs = [ops.split_bf3(torch.randn(M, K, device="cuda")) for _ in range(G)]
-        ws = [ops.split_bf3(torch.randn(N, K, device="cuda") * K ** -0.5) for _ in range(G)]
+        ws = [ops.split_bf3_w(torch.randn(N, K, device="cuda") * K ** -0.5) for _ in range(G)]
         bs = [torch.randn(N, device="cuda") for _ in range(G)]
         row = []
         for t in tiles:

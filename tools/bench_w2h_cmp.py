@@ -10,7 +10,7 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 for M, N, K in [(64512, 4096, 1024), (64512, 1024, 1024), (64512, 768, 768)]:
-    x3 = ops.split_bf3(torch.randn(M, K, device="cuda")); w3 = ops.split_bf3(torch.randn(N, K, device="cuda") * K ** -0.5)
+    x3 = ops.split_bf3(torch.randn(M, K, device="cuda")); w3 = ops.split_bf3_w(torch.randn(N, K, device="cuda") * K ** -0.5)
     b = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda")
     for tile in ("0", "3"):
         os.environ["A3R_BF3_TILE"] = tile

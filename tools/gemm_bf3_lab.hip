@@ -21,7 +21,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS image of one operand stage: rows of U = 3*BK/8 16-byte units, unpadded, with the units of each row rotated on the
 // source side so that the MFMA operand reads (ds_read_b128) are conflict-free.
-// VAR bits: 1 = s_setprio(1) around the MFMA cluster; 2 = v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (BK must be 32)
+// VAR bits: 1 = s_setprio(1) around the MFMA cluster; 2 = v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (BK must be 32);
+// 4 = no DMA after the prologue; 8 = only the a0b0 product; 16 = no MFMA at all; 32 = TIMING ONLY: sources addressed as if both
+// operands were stored pre-tiled (a stage of a tile = one contiguous block), results are meaningless
 template <int BM, int BN, int BK, int WM, int WN, int NS, int VAR>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restrict__ Ap, const uint16_t* __restrict__ Wp, float* __restrict__ C,
                                                           int M, int N, int K) {
@@ -41,10 +43,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const size_t pitch = (size_t)K * 6;                // bytes per bf3 row
+    const size_t pitch = (size_t)K * 6 + ((VAR & 512) ? 128 : 0);   // bytes per bf3 row (VAR & 512: one extra cache line, so rows start on rotating L2 channels)
     // source-side rotation: 32x32x16 operands rotate single units by (r / PER) % G; 16x16x32 operands (BK = 32) rotate whole
     // k-groups (3 units) by 2 * ((r >> 3) & 1)
-    auto src_unit = [&](int r, int cp) { return M16 ? (cp + 6 * ((r >> 3) & 1)) % U : (cp + (r / PER) % G) % U; };
+    // VAR & 4096: the rotation is baked into the storage (rows with bit 3 set keep their k-groups rotated by two), the DMA is lane-linear
+    auto src_unit = [&](int r, int cp) { return (VAR & 4096) ? cp : M16 ? (cp + 6 * ((r >> 3) & 1)) % U : (cp + (r / PER) % G) % U; };
     const char* srcA[LA];
     const char* srcB[LB];
 #pragma unroll
@@ -57,19 +60,57 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3(const uint16_t* __restr
         const int slot = tid + NT * i, r = (slot / U) % BN, cp = slot % U;
         srcB[i] = reinterpret_cast<const char*>(Wp) + (size_t)(n0 + r) * pitch + src_unit(r, cp) * 16;
     }
+    // row-block interleaved storage [R/RB][K/32][RB rows][12 units]: a block's k-slice is RB*192 contiguous, line-aligned bytes.
+    // VAR & 64: RB = 2 (both operands); VAR & 128: RB = 16 (both); VAR & 256: RB = 16 for W only (A stays row-major)
+    constexpr int RBA = (VAR & 64) ? 2 : (VAR & 128) ? 16 : (VAR & 1024) ? 64 : (VAR & 2048) ? 256 : 1;
+    constexpr int RBB = (VAR & 64) ? 2 : (VAR & (128 | 256)) ? 16 : (VAR & 1024) ? 64 : (VAR & 2048) ? 128 : 1;
+    if (RBA > 1) {
+#pragma unroll
+        for (int i = 0; i < LA; i++) {
+            const int slot = tid + NT * i, r = (slot / U) % BM, cp = slot % U, gm = m0 + r;
+            srcA[i] = reinterpret_cast<const char*>(Ap) + (size_t)(gm / RBA) * (RBA * pitch) + (gm % RBA) * 192 + src_unit(r, cp) * 16;
+        }
+    }
+    if (RBB > 1) {
+#pragma unroll
+        for (int i = 0; i < LB; i++) {
+            const int slot = tid + NT * i, r = (slot / U) % BN, cp = slot % U, gn = n0 + r;
+            srcB[i] = reinterpret_cast<const char*>(Wp) + (size_t)(gn / RBB) * (RBB * pitch) + (gn % RBB) * 192 + src_unit(r, cp) * 16;
+        }
+    }
+    if (VAR & 32) {
+        const int nkk = K / BK;
+#pragma unroll
+        for (int i = 0; i < LA; i++) srcA[i] = reinterpret_cast<const char*>(Ap) + ((size_t)tile_m * nkk * SA + (size_t)((tid + NT * i) % SA)) * 16;
+#pragma unroll
+        for (int i = 0; i < LB; i++) srcB[i] = reinterpret_cast<const char*>(Wp) + ((size_t)tile_n * nkk * SB + (size_t)((tid + NT * i) % SB)) * 16;
+    }
     const bool lastA = (LA - 1) * NT + wave * 64 < SA, lastB = (LB - 1) * NT + wave * 64 < SB;   // wave-uniform
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;
-        const size_t koff = (size_t)kt * (KG * 48);
+        const size_t koffA = (size_t)kt * (KG * 48) * RBA, koffB = (size_t)kt * (KG * 48) * RBB;
+        if (VAR & 32) {
+#pragma unroll
+            for (int i = 0; i < LA; i++)
+                if (i + 1 < LA || SA % NT == 0 || lastA)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (size_t)kt * SA * 16),
+                                                     (__attribute__((address_space(3))) void*)(base + NT * 16 * i), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < LB; i++)
+                if (i + 1 < LB || SB % NT == 0 || lastB)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (size_t)kt * SB * 16),
+                                                     (__attribute__((address_space(3))) void*)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LA; i++)
             if (i + 1 < LA || SA % NT == 0 || lastA)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koffA),
                                                  (__attribute__((address_space(3))) void*)(base + NT * 16 * i), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < LB; i++)
             if (i + 1 < LB || SB % NT == 0 || lastB)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + koff),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + koffB),
                                                  (__attribute__((address_space(3))) void*)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
     };
     // per-wave loads per stage (wave-uniform)
@@ -241,6 +282,21 @@ static void split_rows(const std::vector<float>& X, std::vector<uint16_t>& P, in
         }
 }
 
+static void split_rows_blk(const std::vector<float>& X, std::vector<uint16_t>& P, int R, int K, int RB, int pad = 0, bool baked = false) {
+    const size_t pitch = (size_t)6 * K + pad;
+    P.assign((size_t)((R + RB - 1) / RB) * RB * pitch / 2, 0);
+    for (int n = 0; n < R; n++)
+        for (int k = 0; k < K; k++) {
+            float x = X[(size_t)n * K + k];
+            uint16_t p0 = bf16_rne(x); float r1 = x - bf16_f(p0);
+            uint16_t p1 = bf16_rne(r1); float r2 = r1 - bf16_f(p1);
+            uint16_t p2 = bf16_rne(r2);
+            // bytes: (n/RB) * RB*6K + (k>>5) * RB*192 + (n%RB) * 192 + ((k>>3)&3) * 48 + plane * 16 + (k&7) * 2
+            size_t base = ((size_t)(n / RB) * RB * pitch + (size_t)(k >> 5) * RB * 192 + (n % RB) * 192 + ((((k >> 3) & 3) + (baked && ((n >> 3) & 1) ? 2 : 0)) & 3) * 48) / 2 + (k % 8);
+            P[base] = p0; P[base + 8] = p1; P[base + 16] = p2;
+        }
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int NS, int VAR = 0>
 double run(const char* name, const uint16_t* Ap, const uint16_t* Wp, float* C, int M, int N, int K, int iters) {
     auto kern = gemm_bf3<BM, BN, BK, WM, WN, NS, VAR>;
@@ -278,7 +334,7 @@ int main(int argc, char** argv) {
         std::vector<uint16_t> hAp, hWp;
         split_rows(hA, hAp, M, K); split_rows(hW, hWp, N, K);
         uint16_t *Ap, *Wp; float* C;
-        CK(hipMalloc(&Ap, hAp.size() * 2)); CK(hipMalloc(&Wp, hWp.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4));
+        CK(hipMalloc(&Ap, hAp.size() * 2 + (size_t)(M + 16) * 128)); CK(hipMalloc(&Wp, hWp.size() * 2 + (size_t)(N + 16) * 128)); CK(hipMalloc(&C, (size_t)M * N * 4));
         CK(hipMemcpy(Ap, hAp.data(), hAp.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(Wp, hWp.data(), hWp.size() * 2, hipMemcpyHostToDevice));
         const int it = 20;
@@ -299,6 +355,46 @@ int main(int argc, char** argv) {
         int bit = 0;
 #define RUN(name, ...) do { if (mask & (1u << bit)) { run<__VA_ARGS__>(name, Ap, Wp, C, M, N, K, it); check(name); } bit++; } while (0)
         RUN("256x128 16w m16 NS2", 256, 128, 32, 4, 4, 2, 2);
+        RUN("256x128 16w m16 NS2 TILED-SRC", 256, 128, 32, 4, 4, 2, 2 | 32);
+        auto upload = [&](int rba, int rbb, int pad = 0, bool baked = false) {
+            std::vector<uint16_t> hA2, hW2;
+            split_rows_blk(hA, hA2, M, K, rba, pad, baked); split_rows_blk(hW, hW2, N, K, rbb, pad, baked);
+            CK(hipMemcpy(Ap, hA2.data(), hA2.size() * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(Wp, hW2.data(), hW2.size() * 2, hipMemcpyHostToDevice));
+        };
+        upload(2, 2);
+        RUN("256x128 16w m16 NS2 RB2", 256, 128, 32, 4, 4, 2, 2 | 64);
+        upload(16, 16);
+        RUN("256x128 16w m16 NS2 RB16", 256, 128, 32, 4, 4, 2, 2 | 128);
+        RUN("128x64 4w m16 NS2 RB16", 128, 64, 32, 2, 2, 2, 2 | 128);
+        RUN("64x64 4w m16 NS3 RB16", 64, 64, 32, 2, 2, 3, 2 | 128);
+        upload(1, 16);
+        RUN("256x128 16w m16 NS2 RB16 W only", 256, 128, 32, 4, 4, 2, 2 | 256);
+        upload(1, 1, 0, true);
+        RUN("256x128 16w m16 NS2 RB1 BAKED", 256, 128, 32, 4, 4, 2, 2 | 4096);
+        upload(2, 2, 0, true);
+        RUN("256x128 16w m16 NS2 RB2 BAKED", 256, 128, 32, 4, 4, 2, 2 | 64 | 4096);
+        RUN("128x64 4w m16 NS2 RB2 BAKED", 128, 64, 32, 2, 2, 2, 2 | 64 | 4096);
+        RUN("64x64 4w m16 NS3 RB2 BAKED", 64, 64, 32, 2, 2, 3, 2 | 64 | 4096);
+        upload(16, 16, 0, true);
+        RUN("256x128 16w m16 NS2 RB16 BAKED", 256, 128, 32, 4, 4, 2, 2 | 128 | 4096);
+        upload(256, 128, 0, true);
+        RUN("256x128 16w m16 NS2 RB256/128 BAKED", 256, 128, 32, 4, 4, 2, 2 | 2048 | 4096);
+        upload(64, 64);
+        RUN("256x128 16w m16 NS2 RB64", 256, 128, 32, 4, 4, 2, 2 | 1024);
+        upload(256, 128);
+        RUN("256x128 16w m16 NS2 RB256/128", 256, 128, 32, 4, 4, 2, 2 | 2048);
+        upload(1, 1, 128);
+        RUN("256x128 16w m16 NS2 PAD128", 256, 128, 32, 4, 4, 2, 2 | 512);
+        RUN("128x64 4w m16 NS2 PAD128", 128, 64, 32, 2, 2, 2, 2 | 512);
+        RUN("64x64 4w m16 NS3 PAD128", 64, 64, 32, 2, 2, 3, 2 | 512);
+        upload(2, 2, 128);
+        RUN("256x128 16w m16 NS2 RB2 PAD128", 256, 128, 32, 4, 4, 2, 2 | 64 | 512);
+        upload(1, 1);
+        RUN("128x64 4w m16 NS2 (row-major)", 128, 64, 32, 2, 2, 2, 2);
+        RUN("64x64 4w m16 NS3 (row-major)", 64, 64, 32, 2, 2, 3, 2);
+        RUN("256x128 16w m16 NS2 noMFMA", 256, 128, 32, 4, 4, 2, 2 | 16);
+        RUN("256x128 16w m16 NS2 noMFMA TILED-SRC", 256, 128, 32, 4, 4, 2, 2 | 16 | 32);
         RUN("256x256x16 8w(4x2) m32 NS3", 256, 256, 16, 4, 2, 3, 0);
         RUN("256x256x16 8w(2x4) m32 NS3", 256, 256, 16, 2, 4, 3, 0);
         RUN("256x256x16 16w(4x4) m32 NS3", 256, 256, 16, 4, 4, 3, 0);
