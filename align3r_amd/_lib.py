@@ -20,7 +20,7 @@ class Epilogue(C.Structure):
     _fields_ = [("epi", C.c_int), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("relu_a", C.c_int),
                 ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
-                ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int)]
+                ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int)]
 
 
 class GroupPtrs(C.Structure):
@@ -76,7 +76,7 @@ SIGNATURES = {
     "a3r_split_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),
     "a3r_bf3_w_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "a3r_split_bf3_w": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),
-    "a3r_layernorm_bf3": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
+    "a3r_layernorm_bf3": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, C.c_int, c_void]),
     "a3r_linear_bf3": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_linear_bf3_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_conv3x3_bf3": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
@@ -84,7 +84,7 @@ SIGNATURES = {
     "a3r_pack_conv3x3": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void]),
     "a3r_pack_convT": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_attention": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
-    "a3r_attention_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_attention_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_rope_table_host": (C.c_int, [c_void, c_void, C.c_int, C.c_float]),
     "a3r_patchify": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, c_void]),
     "a3r_upsample2x": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),

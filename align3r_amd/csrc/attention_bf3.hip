@@ -41,6 +41,7 @@ struct Attn3Args {
     char* o;
     size_t pq, pk, pv, po;                  // row pitches in bytes (6 x leading dimension)
     int B, H, Nq, Nk;
+    int ldo, out_pair;                      // o: leading dimension in elements; row-pair layout (bf3.h) for a GEMM-only consumer
 };
 
 typedef const __attribute__((address_space(1))) void* a3_gptr;
@@ -236,14 +237,14 @@ __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(At
     const float inv_l = 1.f / l_tot;
     if (q_row < a.Nq) {
         // lane (query, half) holds d = 32 db + 8 g + 4 half + (0..3): half a bf3 unit per plane
-        char* op = a.o + ((size_t)b * a.Nq + q_row) * a.po + h * 384;
+        char* op = a.o + bf3_row_offset((long)b * a.Nq + q_row, a.ldo, a.out_pair);
 #pragma unroll
         for (int db = 0; db < 2; db++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const f32x4 v = {oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l, oacc[db][4 * g + 2] * inv_l,
                                  oacc[db][4 * g + 3] * inv_l};
-                bf3_store4(op, db * 32 + 8 * g + 4 * half, v);
+                bf3_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v, a.out_pair);
             }
     }
 }
@@ -252,11 +253,12 @@ __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(At
 using namespace a3r;
 
 extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
-                                 int B, int H, int Nq, int Nk, void* stream) {
+                                 int B, int H, int Nq, int Nk, int out_pair, void* stream) {
     A3R_CHECK_ARG(q3 && k3 && v3 && o3, "a3r_attention_bf3: null pointer");
     A3R_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "a3r_attention_bf3: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     A3R_CHECK_ARG(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ldo >= H * 64, "a3r_attention_bf3: row strides < H*64");
     A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_bf3: row strides must be multiples of 8");
+    A3R_CHECK_ARG(!out_pair || ldo % 32 == 0, "a3r_attention_bf3: the row-pair output layout needs ldo %% 32 == 0");
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q3) | reinterpret_cast<uintptr_t>(k3) | reinterpret_cast<uintptr_t>(v3) |
                     reinterpret_cast<uintptr_t>(o3)) & 15) == 0, "a3r_attention_bf3: pointers must be 16-byte aligned");
     static bool attr_done = false;
@@ -267,7 +269,7 @@ extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ld
         attr_done = true;
     }
     Attn3Args a = {static_cast<const char*>(q3), static_cast<const char*>(k3), static_cast<const char*>(v3), static_cast<char*>(o3),
-                   (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk};
+                   (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk, ldo, out_pair ? 1 : 0};
     const int nqb = (Nq + A3Q - 1) / A3Q, groups = B * H;
     dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION_BF3, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));

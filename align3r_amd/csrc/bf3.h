@@ -19,6 +19,14 @@ namespace a3r {
 
 __host__ __device__ inline size_t bf3_w_row_offset(int n, int K) { return (size_t)(n >> 1) * ((size_t)12 * K) + (size_t)(n & 1) * 192; }
 constexpr int BF3_W_KBLOCK_BYTES = 384;      // one 32-deep k block of a weight row pair
+// The same row-pair form serves ACTIVATION matrices that are only ever read as the A operand of a GEMM (`pair` != 0 below): the
+// outputs of LayerNorm, of the attention kernel and of the fc1 + GELU epilogue in the transformer blocks.  pair == 0: plain rows.
+__host__ __device__ inline size_t bf3_row_offset(long r, int K, int pair) {
+    return pair ? (size_t)(r >> 1) * ((size_t)12 * K) + (size_t)(r & 1) * 192 : (size_t)r * ((size_t)6 * K);
+}
+__host__ __device__ inline int bf3_k_offset(int k, int pair) {        // of the 48-byte group holding k (k % 8 ignored)
+    return pair ? (k >> 5) * 384 + ((k >> 3) & 3) * 48 : (k >> 3) * 48;
+}
 
 int bf3_products();        // 6 | 3 | 1: the process-wide product set of the bf3 kernels (gemm_bf3.hip)
 
@@ -44,8 +52,8 @@ __device__ __forceinline__ void bf3_split2(float a, float b, uint32_t& p0, uint3
 }
 
 // four consecutive k (k0 % 4 == 0) of one bf3 row
-__device__ __forceinline__ void bf3_store4(char* row, int k0, f32x4 v) {
-    char* d = row + (k0 >> 3) * 48 + ((k0 >> 2) & 1) * 8;
+__device__ __forceinline__ void bf3_store4(char* row, int k0, f32x4 v, int pair = 0) {
+    char* d = row + bf3_k_offset(k0, pair) + ((k0 >> 2) & 1) * 8;
     uint32_t a0, a1, a2, b0, b1, b2;
     bf3_split2(v.x, v.y, a0, a1, a2);
     bf3_split2(v.z, v.w, b0, b1, b2);
@@ -55,8 +63,8 @@ __device__ __forceinline__ void bf3_store4(char* row, int k0, f32x4 v) {
 }
 
 // eight consecutive k (k0 % 8 == 0) of one bf3 row: 48 contiguous bytes
-__device__ __forceinline__ void bf3_store8(char* row, int k0, f32x4 lo, f32x4 hi) {
-    char* d = row + (k0 >> 3) * 48;
+__device__ __forceinline__ void bf3_store8(char* row, int k0, f32x4 lo, f32x4 hi, int pair = 0) {
+    char* d = row + bf3_k_offset(k0, pair);
     uint32_t a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
     bf3_split2(lo.x, lo.y, a0, a1, a2);
     bf3_split2(lo.z, lo.w, b0, b1, b2);

@@ -13,7 +13,8 @@ namespace a3r {
 template <int VPL, bool BF3>   // float4 per lane: D = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ y, int M,
-                                                         int D, float eps) {
+                                                         int D, float eps, int pair) {
+#pragma clang fp contract(off)      // the fp32 and the bf3 instantiation must round identically (bf3 output == split of the fp32 one)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
@@ -35,11 +36,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
     const f32x4* wr = reinterpret_cast<const f32x4*>(w);
     const f32x4* br = reinterpret_cast<const f32x4*>(b);
-    char* y3 = reinterpret_cast<char*>(y) + (size_t)row * D * 6;
+    char* y3 = reinterpret_cast<char*>(y) + bf3_row_offset(row, D, pair);
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
-        const f32x4 o = v[i] * rstd * wr[lane + 64 * i] + br[lane + 64 * i];
-        if (BF3) bf3_store4(y3, (lane + 64 * i) * 4, o);
+        // explicit fma: the fp32 and the bf3 instantiation must round identically (bf3 output == split of the fp32 output, tested)
+        const f32x4 t = v[i] * rstd, wv = wr[lane + 64 * i], bv = br[lane + 64 * i];
+        const f32x4 o = {__builtin_fmaf(t.x, wv.x, bv.x), __builtin_fmaf(t.y, wv.y, bv.y), __builtin_fmaf(t.z, wv.z, bv.z),
+                         __builtin_fmaf(t.w, wv.w, bv.w)};
+        if (BF3) bf3_store4(y3, (lane + 64 * i) * 4, o, pair);
         else yr[lane + 64 * i] = o;
     }
 }
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <bool BF3>
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ y, int M,
-                                                                 int D, float eps) {
+                                                                 int D, float eps, int pair) {
+#pragma clang fp contract(off)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* xr = x + (size_t)row * D;
@@ -59,16 +64,16 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
     for (int i = lane; i < D; i += 64) { const float c = xr[i] - mean; ss += c * c; }
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
     if (BF3) {
-        char* y3 = reinterpret_cast<char*>(y) + (size_t)row * D * 6;
+        char* y3 = reinterpret_cast<char*>(y) + bf3_row_offset(row, D, pair);
         for (int i = lane * 4; i < D; i += 256) {
             f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; j++) o[j] = (xr[i + j] - mean) * rstd * w[i + j] + b[i + j];
-            bf3_store4(y3, i, o);
+            for (int j = 0; j < 4; j++) o[j] = __builtin_fmaf((xr[i + j] - mean) * rstd, w[i + j], b[i + j]);
+            bf3_store4(y3, i, o, pair);
         }
     } else {
         float* yr = y + (size_t)row * D;
-        for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * w[i] + b[i];
+        for (int i = lane; i < D; i += 64) yr[i] = __builtin_fmaf((xr[i] - mean) * rstd, w[i], b[i]);
     }
 }
 
@@ -268,14 +273,14 @@ extern "C" int a3r_umeyama_moments(const float* x, const float* y, const float* 
 }
 
 template <bool BF3>
-static int launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps, void* stream) {
+static int launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, int D, float eps, void* stream, int pair = 0) {
     hipStream_t st = as_stream(stream);
     ProfScope prof(PK_LAYERNORM, (BF3 ? 10.0 : 8.0) * M * D, st);
     dim3 grid((M + 3) / 4), block(256);
-    if (D == 1024) hipLaunchKernelGGL((layernorm_kernel<4, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (D == 768) hipLaunchKernelGGL((layernorm_kernel<3, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (D == 256) hipLaunchKernelGGL((layernorm_kernel<1, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps);
-    else hipLaunchKernelGGL(layernorm_generic_kernel<BF3>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    if (D == 1024) hipLaunchKernelGGL((layernorm_kernel<4, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps, pair);
+    else if (D == 768) hipLaunchKernelGGL((layernorm_kernel<3, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps, pair);
+    else if (D == 256) hipLaunchKernelGGL((layernorm_kernel<1, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps, pair);
+    else hipLaunchKernelGGL(layernorm_generic_kernel<BF3>, grid, block, 0, st, x, w, b, y, M, D, eps, pair);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -287,12 +292,13 @@ extern "C" int a3r_layernorm(const float* x, const float* w, const float* b, flo
     return launch_layernorm<false>(x, w, b, y, M, D, eps, stream);
 }
 
-extern "C" int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps,
+extern "C" int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps, int pair,
                                  void* stream) {
     A3R_CHECK_ARG(x && w && b && y3, "a3r_layernorm_bf3: null pointer");
     A3R_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0, "a3r_layernorm_bf3: bad shape M=%d D=%d (D must be a multiple of 8)", M, D);
+    A3R_CHECK_ARG(!pair || D % 32 == 0, "a3r_layernorm_bf3: the row-pair layout needs D (%d) to be a multiple of 32", D);
     A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(y3) & 15) == 0, "a3r_layernorm_bf3: y3 must be 16-byte aligned");
-    return launch_layernorm<true>(x, w, b, static_cast<float*>(y3), M, D, eps, stream);
+    return launch_layernorm<true>(x, w, b, static_cast<float*>(y3), M, D, eps, stream, pair ? 1 : 0);
 }
 
 extern "C" int a3r_rope2d(float* tokens, const int64_t* positions, int B, int N, int H, int D, float base, float fwd,

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
         const int slot = tid + NT * i, r = (slot / U) % BM, cp = slot % U;
         const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
         if (AMODE == 0) {
-            srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + src_unit(r, cp) * 16;
+            srcA[i] = reinterpret_cast<const char*>(P.A) + bf3_row_offset(gm, g.K, g.epi.x_pair) + src_unit(r, cp) * 16;
             tapsA[i] = 0;
         } else {
             const int hw = g.cHo * g.cWo;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
     int c_tap = 0, c_ci = 0;                                          // AMODE 1: (tap, first channel) of the next stage to issue (stages are issued in order)
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
-        const size_t koff = (size_t)kt * (KG * 48);
+        const size_t koff = (size_t)kt * (KG * 48) * (AMODE == 0 && g.epi.x_pair ? 2 : 1);
         long delta = 0;
         if (AMODE == 1) {
             const int dy = c_tap / 3, dx = c_tap - 3 * dy;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm_bf3_w2h_kernel(GemmArgs g) {
     for (int i = 0; i < LA; i++) {
         const int slot = tid + NT * i, r = slot / U, cp = slot % U;
         const int rr = FULL ? r : min(m0 + r, g.M - 1) - m0;
-        offA[i] = (unsigned)(rr * pitch) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;
+        offA[i] = (unsigned)bf3_row_offset(rr, g.K, g.epi.x_pair) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;        // relative to row m0 (even)
     }
 #pragma unroll
     for (int h = 0; h < 2; h++)
@@ -298,11 +298,11 @@ __global__ __launch_bounds__(512) void gemm_bf3_w2h_kernel(GemmArgs g) {
             const int rr = FULL ? h * HN + r : min(n0 + h * HN + r, g.N - 1) - n0;
             offW[h][i] = (unsigned)bf3_w_row_offset(rr, g.K) + ((cp + 6 * ((r >> 3) & 1)) % U) * 16;      // relative to row n0 (even)
         }
-    const char* Abase = reinterpret_cast<const char*>(P.A) + (size_t)m0 * pitch;
+    const char* Abase = reinterpret_cast<const char*>(P.A) + bf3_row_offset(m0, g.K, g.epi.x_pair);
     const char* Wbase = reinterpret_cast<const char*>(P.Wt) + bf3_w_row_offset(n0, g.K);            // n0 is a multiple of 256
     auto issue_a = [&](int kt, int buf) {
         char* base = As + buf * A_BYTES + wave * 1024;
-        const char* src = Abase + (size_t)kt * 192;
+        const char* src = Abase + (size_t)kt * (g.epi.x_pair ? 384 : 192);
 #pragma unroll
         for (int i = 0; i < LA; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + offA[i]), (lptr_t)(base + NT * 16 * i), 16, 0, 0);
     };
@@ -563,6 +563,7 @@ extern "C" int a3r_conv3x3_bf3(const void* x3, const void* wp3, float* y, int B,
     if (epi) g.epi = *epi;
     A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF && g.epi.epi != A3R_EPI_ROPE, "a3r_conv3x3_bf3: unsupported epilogue");
     A3R_CHECK_ARG(!g.epi.relu_a, "a3r_conv3x3_bf3: relu_a is not available (the producer writes the pre-activated bf3 input: aux_relu)");
+    A3R_CHECK_ARG(!g.epi.x_pair && !g.epi.out_pair, "a3r_conv3x3_bf3: the row-pair layout is for a3r_linear_bf3 operands only");
     g.groups = 1;
     g.grp[0] = {static_cast<const float*>(x3), static_cast<const float*>(wp3), y, g.epi.bias, g.epi.resid, g.epi.resid2};
     if (int rc = check_group(g.grp[0], g.epi.epi, "a3r_conv3x3_bf3")) return rc;

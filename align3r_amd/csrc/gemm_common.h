@@ -101,6 +101,7 @@ __device__ __forceinline__ void gemm_epilogue16_body(const GemmArgs& g, const Gr
     char* out3 = O3 == 0 ? nullptr : (only3 ? reinterpret_cast<char*>(P.C) : static_cast<char*>(ep.aux_bf3));
     const bool relu3 = !only3 && ep.aux_relu;
     const size_t pitch3 = (size_t)g.N * 6;
+    const int pair3 = only3 && ep.out_pair;                               // out_bf3 in the row-pair layout (bf3.h)
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int colbase = n0 + wcol0 + j * 16;
@@ -157,7 +158,8 @@ __device__ __forceinline__ void gemm_epilogue16_body(const GemmArgs& g, const Gr
                 const float a1 = odd ? r1 : v[1], b1 = odd ? v[3] : r1;
                 const int row0 = m0 + wrow0 + i * 16 + quad * 4 + (odd ? 2 : 0);
                 const int c0 = col & ~1;                                      // N % 8 == 0: a column pair is in or out together
-                char* d = out3 + (size_t)row0 * pitch3 + (c0 >> 3) * 48 + (c0 & 7) * 2;
+                char* d = out3 + bf3_row_offset(row0, g.N, pair3) + bf3_k_offset(c0, pair3) + (c0 & 7) * 2;      // row0 is even
+                const size_t next_row = pair3 ? 192 : pitch3;
                 uint32_t p0, p1, p2;
                 if (col_ok && (FULL || row0 < g.M)) {
                     bf3_split2(a0, b0, p0, p1, p2);
@@ -167,9 +169,9 @@ __device__ __forceinline__ void gemm_epilogue16_body(const GemmArgs& g, const Gr
                 }
                 if (col_ok && (FULL || row0 + 1 < g.M)) {
                     bf3_split2(a1, b1, p0, p1, p2);
-                    *reinterpret_cast<uint32_t*>(d + pitch3) = p0;
-                    *reinterpret_cast<uint32_t*>(d + pitch3 + 16) = p1;
-                    *reinterpret_cast<uint32_t*>(d + pitch3 + 32) = p2;
+                    *reinterpret_cast<uint32_t*>(d + next_row) = p0;
+                    *reinterpret_cast<uint32_t*>(d + next_row + 16) = p1;
+                    *reinterpret_cast<uint32_t*>(d + next_row + 32) = p2;
                 }
             }
         }
@@ -202,6 +204,9 @@ static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char
         A3R_CHECK_ARG(N % 8 == 0 && (e->epi == A3R_EPI_NONE || e->epi == A3R_EPI_GELU || e->epi == A3R_EPI_RELU || e->epi == A3R_EPI_ROPE),
                       "%s: out_bf3 needs N %% 8 == 0 and a NONE / GELU / RELU / ROPE epilogue", who);
         A3R_CHECK_ARG(!e->aux_bf3, "%s: out_bf3 and aux_bf3 are exclusive", who);
+        A3R_CHECK_ARG(!e->out_pair || N % 32 == 0, "%s: out_pair needs N %% 32 == 0", who);
+    } else {
+        A3R_CHECK_ARG(!e->out_pair, "%s: out_pair without out_bf3", who);
     }
     if (e->aux_bf3) {
         A3R_CHECK_ARG(bf3_kernel, "%s: aux_bf3 is only available on the bf3 kernels", who);

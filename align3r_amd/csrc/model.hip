@@ -386,6 +386,9 @@ struct Plan {
     }
     // ---- "GEMM input" (gin) buffers: [rows, K] fp32 in f32 mode, the bf3 form of it (1.5x the bytes, bf3.h) otherwise
     bool bf3() const { return m->use_bf3; }
+    // bf3 mode: buffers that are only ever read as the A operand of a GEMM (LayerNorm / attention / fc1+GELU outputs, split
+    // activations) are kept in the row-pair form of the layout (bf3.h) when the row counts of both views are even
+    bool pair = false;
     float* gin_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
     float* gin_scratch(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : 0); }     // only needed for splitting
     template <class T> T* gin_at(T* base, size_t rows, int K) const { return base + (bf3() ? rows * K * 3 / 2 : rows * K); }
@@ -398,7 +401,7 @@ struct Plan {
         if (!bf3()) return x;
         if (skip()) return scratch;
         traced("split_bf3", (int)M, K);
-        rc = a3r_split_bf3(x, K, scratch, M, K, stream);
+        rc = pair ? a3r_split_bf3_w(x, K, scratch, M, K, stream) : a3r_split_bf3(x, K, scratch, M, K, stream);
         return scratch;
     }
     const void* twin(const float* w) {
@@ -410,14 +413,18 @@ struct Plan {
         }
         return it->second;
     }
-    // nn.Linear on a GEMM-input buffer (bf3 MFMA path unless A3R_GEMM=f32)
-    void linear(const float* xg, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e) {
+    // nn.Linear on a GEMM-input buffer (bf3 MFMA path unless A3R_GEMM=f32); plain_x: xg is a plain-rows bf3 matrix (DPT maps)
+    void linear(const float* xg, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e0,
+                bool plain_x = false) {
         if (skip()) return;
         traced("linear", M, N, K);
         if (bf3()) {
             const void* w3 = twin(w);
+            a3r_epilogue e = e0;
+            e.x_pair = (pair && !plain_x) ? 1 : 0;
             if (w3) rc = a3r_linear_bf3(xg, w3, y, ldc, M, N, K, &e, stream);
         } else {
+            const a3r_epilogue& e = e0;
             rc = a3r_linear(xg, lda, w, y, ldc, M, N, K, &e, stream);
         }
     }
@@ -437,6 +444,7 @@ struct Plan {
             const void *w30 = twin(w0), *w31 = twin(w1);
             if (!w30 || !w31) return;
             a3r_group_ptrs_bf3 g[2] = {{x0, w30, y0, b0, r0, nullptr}, {x1, w31, y1, b1, r1, nullptr}};
+            e.x_pair = pair ? 1 : 0;
             rc = a3r_linear_bf3_grouped(g, 2, ldc, M, N, K, &e, stream);
         } else {
             a3r_group_ptrs g[2] = {{x0, w0, y0, b0, r0, nullptr}, {x1, w1, y1, b1, r1, nullptr}};
@@ -465,7 +473,7 @@ struct Plan {
     void ln(const float* x, const float* w, const float* b, float* yg, int M, int D) {
         if (skip()) return;
         traced("layernorm", M, D);
-        rc = bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
+        rc = bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, pair, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
     }
     void ln_f32(const float* x, const float* w, const float* b, float* y, int M, int D) {
         if (skip()) return;
@@ -476,7 +484,7 @@ struct Plan {
     void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
         if (skip()) return;
         traced("attention", B, Nq, Nk);
-        rc = bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream)
+        rc = bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, pair, stream)
                    : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
     }
     void conv(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
@@ -512,6 +520,7 @@ struct Plan {
     a3r_epilogue gin_epi(int kind, const float* bias) {
         a3r_epilogue e = epi(kind, bias);
         e.out_bf3 = bf3() ? 1 : 0;
+        e.out_pair = (bf3() && pair) ? 1 : 0;
         return e;
     }
     void mlp(const BlockW& w, const float* nw, const float* nb, float* x, int M, int D, int hidden, float* xn, float* hid) {
@@ -593,7 +602,7 @@ float* fusion_bf3(Plan& P, const FusionW& w, const float* x0, const float* x0r3,
         float* r;
         if (last) { r = P.alloc3(opx, F); e.out_bf3 = 1; }
         else r = ar.alloc(opx * F);
-        P.linear(u3, F, w.ow, r, F, (int)opx, F, F, e);
+        P.linear(u3, F, w.ow, r, F, (int)opx, F, F, e, /*plain_x=*/true);
         return r;
     }
     // out_conv (1x1, dpt_block.py:216) is applied BEFORE the bilinear 2x instead of after it: both are linear maps over
@@ -603,7 +612,7 @@ float* fusion_bf3(Plan& P, const FusionW& w, const float* x0, const float* x0r3,
     float* o3 = P.alloc3(px, F);
     rcu_bf3(P, w.r2, cur, cur3, nullptr, tmp3, o, o3, B, H, W, F, /*aux_relu=*/false);
     float* lo = ar.alloc(n);
-    P.linear(o3, F, w.ow, lo, F, (int)px, F, F, P.epi(A3R_EPI_NONE, w.ob));
+    P.linear(o3, F, w.ow, lo, F, (int)px, F, F, P.epi(A3R_EPI_NONE, w.ob), /*plain_x=*/true);
     const size_t opx = (size_t)B * Hc * Wc;
     float* r;
     if (last) {
@@ -632,6 +641,8 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     } products_guard(!dry && m->use_bf3, m->products);
     Plan P;
     P.m = m; P.stream = stream;
+    static const bool plain_act = getenv("A3R_BF3_PLAIN_ACT") != nullptr;      // A/B switch: keep every activation in plain rows
+    P.pair = m->use_bf3 && BN % 2 == 0 && !plain_act;
     P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};
     Arena& ar = P.ar;
     if (phase == 1) {

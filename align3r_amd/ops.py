@@ -66,9 +66,10 @@ def layernorm(x, w, b, eps=1e-6, out=None):
 
 
 def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
-                  aux_bf3=None, aux_relu=False):
+                  aux_bf3=None, aux_relu=False, out_pair=False):
     e = Epilogue()
     e.out_bf3 = int(out_bf3)
+    e.out_pair = int(out_pair)
     e.aux_bf3 = None if aux_bf3 is None else aux_bf3.data_ptr()
     e.aux_relu = int(aux_relu)
     e.epi = kind
@@ -125,7 +126,7 @@ class Bf3:
     """An fp32 matrix [rows, K] in bf3 form (three exact bf16 planes, include/a3r.h): uint8 storage + logical shape."""
 
     def __init__(self, data: torch.Tensor, rows: int, K: int, weight: bool = False):
-        self.data, self.rows, self.K, self.weight = data, rows, K, weight          # weight: the row-pair weight layout
+        self.data, self.rows, self.K, self.weight = data, rows, K, weight          # weight: the row-pair layout (include/a3r.h)
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -165,14 +166,14 @@ def _need_weight_layout(w3, who):
         raise RuntimeError(f"{who}: the weight operand must be in the row-pair weight layout (ops.split_bf3_w)")
 
 
-def layernorm_bf3(x, w, b, eps=1e-6) -> Bf3:
-    """nn.LayerNorm over the last dim with the output written in bf3 form (a3r_layernorm_bf3)."""
+def layernorm_bf3(x, w, b, eps=1e-6, pair=False) -> Bf3:
+    """nn.LayerNorm over the last dim with the output written in bf3 form (a3r_layernorm_bf3); pair: in the row-pair layout."""
     _req(x, "x")
     D = x.shape[-1]
     M = x.numel() // D
-    y = torch.empty(M * D * 6, device=x.device, dtype=torch.uint8)
-    check(_lib.load().a3r_layernorm_bf3(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(y), M, D, eps, stream_ptr()), "layernorm_bf3")
-    return Bf3(y, M, D)
+    y = torch.zeros((M + (M & 1 if pair else 0)) * D * 6, device=x.device, dtype=torch.uint8)      # row pairs: an even number of rows
+    check(_lib.load().a3r_layernorm_bf3(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(y), M, D, eps, int(pair), stream_ptr()), "layernorm_bf3")
+    return Bf3(y, M, D, weight=bool(pair))
 
 
 def linear_bf3(x3: Bf3, w3: Bf3, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
@@ -182,8 +183,9 @@ def linear_bf3(x3: Bf3, w3: Bf3, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
     if w3.K != K:
         raise RuntimeError(f"linear_bf3: K mismatch ({K} vs {w3.K})")
     e = make_epilogue(epi, bias, **kw)
+    e.x_pair = int(x3.weight)
     if e.out_bf3:          # y in bf3 form, for the next bf3 GEMM
-        y3 = Bf3(torch.empty(M * N * 6, device=x3.data.device, dtype=torch.uint8), M, N)
+        y3 = Bf3(torch.zeros((M + (M & 1 if e.out_pair else 0)) * N * 6, device=x3.data.device, dtype=torch.uint8), M, N, weight=bool(e.out_pair))
         check(_lib.load().a3r_linear_bf3(x3.data_ptr(), w3.data_ptr(), y3.data_ptr(), N, M, N, K, C.byref(e), stream_ptr()), "linear_bf3")
         return y3
     if out is None:
@@ -206,6 +208,7 @@ def linear_bf3_grouped(x3s, w3s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
         arr[i].bias = None if biases is None else biases[i].data_ptr()
         arr[i].resid = None if resids is None else resids[i].data_ptr()
     e = make_epilogue(epi, **kw)
+    e.x_pair = int(x3s[0].weight)
     check(_lib.load().a3r_linear_bf3_grouped(arr, G, N, M, N, K, C.byref(e), stream_ptr()), "linear_bf3_grouped")
     return outs
 
@@ -227,12 +230,13 @@ def conv3x3_bf3(x3: Bf3, wp3: Bf3, shape, bias=None, stride=1, epi=_lib.EPI_NONE
     return out
 
 
-def attention_bf3(q3: Bf3, k3: Bf3, v3: Bf3, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0) -> Bf3:
+def attention_bf3(q3: Bf3, k3: Bf3, v3: Bf3, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0, out_pair=False) -> Bf3:
     """softmax(q k^T / 8) v per head (head_dim 64) on bf3 operands; q3/k3/v3 may be column slices (start column, multiple of 8)
     of wider bf3 matrices (e.g. the fused qkv projection).  Returns the bf3 [B*Nq, H*64] output."""
-    o3 = Bf3(torch.empty(B * Nq * H * 64 * 6, device=q3.data.device, dtype=torch.uint8), B * Nq, H * 64)
+    o3 = Bf3(torch.zeros((B * Nq + (B * Nq & 1 if out_pair else 0)) * H * 64 * 6, device=q3.data.device, dtype=torch.uint8), B * Nq, H * 64,
+             weight=bool(out_pair))
     check(_lib.load().a3r_attention_bf3(q3.data_ptr() + q_col * 6, q3.K, k3.data_ptr() + k_col * 6, k3.K, v3.data_ptr() + v_col * 6, v3.K,
-                                        o3.data_ptr(), H * 64, B, H, Nq, Nk, stream_ptr()), "attention_bf3")
+                                        o3.data_ptr(), H * 64, B, H, Nq, Nk, int(out_pair), stream_ptr()), "attention_bf3")
     return o3
 
 

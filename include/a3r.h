@@ -100,6 +100,13 @@ typedef struct {
      * still needed for the skip connection (dpt_block.py:131-141). */
     void* aux_bf3;
     int aux_relu;
+    /* a3r_linear_bf3 only -- operand layouts rather than epilogue options, kept here so the entry points stay as they are:
+     * x_pair: x3 is stored in the ROW-PAIR form (the layout a3r_split_bf3_w documents; produced by a3r_split_bf3_w,
+     * a3r_layernorm_bf3(pair = 1), a3r_attention_bf3(out_pair = 1) or an out_bf3 + out_pair epilogue).  out_pair: with out_bf3, write
+     * y in that form (N % 32 == 0) -- for outputs only ever read as the x3 of another a3r_linear_bf3 (fc1 + GELU -> fc2).
+     * A matrix with an odd number of rows occupies (rows + 1) * K * 6 bytes in this form (a3r_bf3_w_bytes). */
+    int x_pair;
+    int out_pair;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
@@ -142,8 +149,9 @@ int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream)
 size_t a3r_bf3_w_bytes(long rows, int K);
 int a3r_split_bf3_w(const float* w, int ldw, void* y, long N, int K, void* stream);
 /* nn.LayerNorm (as a3r_layernorm) writing its output directly in bf3 form (D % 8 == 0): the producer of every
- * transformer GEMM input (blocks.py:127-130,186-190), fused so the fp32 normalised rows never reach HBM. */
-int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps, void* stream);
+ * transformer GEMM input (blocks.py:127-130,186-190), fused so the fp32 normalised rows never reach HBM.
+ * pair != 0: y3 in the row-pair form (D % 32 == 0), for rows that only feed a3r_linear_bf3 (x_pair). */
+int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps, int pair, void* stream);
 /* x3: bf3 [M, K] (a3r_split_bf3 / a3r_layernorm_bf3 / a bf3 epilogue output); w3: [N, K] in the weight layout (a3r_split_bf3_w) */
 int a3r_linear_bf3(const void* x3, const void* w3, float* y, int ldc, int M, int N, int K, const a3r_epilogue* epi,
                    void* stream);
@@ -180,9 +188,10 @@ int a3r_attention(const float* q, int ldq, const float* k, int ldk, const float*
 /* The same attention on the bf16 matrix cores with fp32 accuracy: q3 / k3 / v3 / o3 are bf3 matrices (pointers to the first
  * column's 48-byte group, leading dimensions in fp32 columns, multiples of 8); six exact bf16 MFMA passes per product,
  * fp32 softmax, P split exactly into three planes in registers.  Consumes the RoPE + out_bf3 output of a3r_linear_bf3 and
- * produces the bf3 input of the output projection. */
+ * produces the bf3 input of the output projection (out_pair != 0: in the row-pair form, ldo % 32 == 0, o3 = the matrix origin;
+ * q3 / k3 / v3 are always plain rows). */
 int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
-                      int B, int H, int Nq, int Nk, void* stream);
+                      int B, int H, int Nq, int Nk, int out_pair, void* stream);
 
 /* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
  * HOST buffers. */

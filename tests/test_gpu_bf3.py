@@ -6,6 +6,8 @@ pin (i) that the split is exact, (ii) that the GEMM error against float64 is not
 kernel's, and (iii) the fused epilogues / ragged shapes / grouped launches against a float64 torch reference.
 Tolerance: 2e-5 relative (same as the fp32 operator tests).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -216,3 +218,45 @@ def test_reduced_product_modes(ops):
         ops.bf3_set_products(6)
     e = rel_err(cpu(low), cpu(exact))
     assert 1e-5 < e < 3e-2, e
+
+
+# ------------------------------------------------------------------------------------------------- row-pair activations
+def test_row_pair_producers_match_plain_ones(ops):
+    """LayerNorm, the fc1 + GELU epilogue and the attention kernel writing the ROW-PAIR layout produce the same planes as their
+    plain-rows outputs (bit for bit), odd row counts included."""
+    from align3r_amd import _lib
+    for M, D in [(10, 1024), (333, 768), (7, 64), (64, 256)]:
+        x, w, b = rnd(M, D, seed=1, scale=2.0), rnd(D, seed=2), rnd(D, seed=3)
+        plain, pair = ops.layernorm_bf3(x, w, b), ops.layernorm_bf3(x, w, b, pair=True)
+        assert pair.weight and torch.equal(pair.planes(), plain.planes())
+    for tile in ("0", "1", "2", "3"):
+        os.environ["A3R_BF3_TILE"] = tile
+        try:
+            for M, N, K in [(300, 192, 96), (256, 256, 64), (1001, 384, 128)]:
+                x3, w3, b = ops.split_bf3(rnd(M, K, seed=1)), ops.split_bf3_w(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
+                plain = ops.linear_bf3(x3, w3, b, epi=_lib.EPI_GELU, out_bf3=True)
+                pair = ops.linear_bf3(x3, w3, b, epi=_lib.EPI_GELU, out_bf3=True, out_pair=True)
+                assert pair.weight and torch.equal(pair.planes(), plain.planes()), (tile, M, N, K)
+        finally:
+            del os.environ["A3R_BF3_TILE"]
+    B, H, Nq, Nk = 3, 2, 77, 50
+    q, k, v = (rnd(B * n, H * 64, seed=s) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    args = (ops.split_bf3(q), ops.split_bf3(k), ops.split_bf3(v), B, H, Nq, Nk)
+    assert torch.equal(ops.attention_bf3(*args, out_pair=True).planes(), ops.attention_bf3(*args).planes())
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.layernorm_bf3(rnd(4, 40, seed=1), rnd(40, seed=2), rnd(40, seed=3), pair=True)
+    with pytest.raises(RuntimeError, match="out_pair"):
+        ops.linear_bf3(ops.split_bf3(rnd(64, 64, seed=1)), ops.split_bf3_w(rnd(40, 64, seed=2)), epi=_lib.EPI_GELU, out_bf3=True, out_pair=True)
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (256, 256, 64), (1001, 384, 128), (768, 1024, 1024)])
+def test_linear_bf3_row_pair_x_operand(ops, monkeypatch, tile, M, N, K):
+    """a3r_linear_bf3 with x3 in the row-pair layout == the same product with x3 in plain rows, bit for bit (same MFMA order)."""
+    monkeypatch.setenv("A3R_BF3_TILE", tile)
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    w3 = ops.split_bf3_w(w)
+    xp = ops.split_bf3_w(x)                      # the row-pair form of an activation is the same layout
+    assert torch.equal(ops.linear_bf3(xp, w3, b), ops.linear_bf3(ops.split_bf3(x), w3, b))
+    outs = ops.linear_bf3_grouped([xp, xp], [w3, w3], [b, b])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], ops.linear_bf3(xp, w3, b))

@@ -37,7 +37,8 @@ def main():
     tot = {t: 0.0 for t in tiles}
     print(f"{'shape':18s} {'M':>7s} {'N':>5s} {'K':>5s} g " + " ".join(f"{'tile ' + t:>22s}" for t in tiles))
     for name, M, N, K, G, cnt in SHAPES:
-        xs = [ops.split_bf3(torch.randn(M, K, device="cuda")) for _ in range(G)]
+        xpair = os.environ.get("A3R_BENCH_XPAIR", "1") != "0" and M % 2 == 0      # the transformer GEMM inputs are row-pair matrices
+        xs = [(ops.split_bf3_w if xpair else ops.split_bf3)(torch.randn(M, K, device="cuda")) for _ in range(G)]
         ws = [ops.split_bf3_w(torch.randn(N, K, device="cuda") * K ** -0.5) for _ in range(G)]
         bs = [torch.randn(N, device="cuda") for _ in range(G)]
         row = []
