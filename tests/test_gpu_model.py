@@ -54,17 +54,23 @@ def test_tiny_vs_reference_golden(tiny_engine, tag, H, W):
         assert rel_err(host(r[k]), t[f"{tag}_{k}"]) < TOL, k
 
 
-def test_tiny_batching_invariance(tiny_engine):
-    """bs=1 twice == bs=2 once (the reference drivers run bs=1; the engine batches pairs)."""
-    v = make_view_arrays(3, 64, 64, seed=4)
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 80)])
+def test_tiny_batching_invariance(tiny_engine, H, W):
+    """bs=1 twice == bs=2 once (the reference drivers run bs=1; the engine batches pairs).  48x80 has 15 tokens per image: a
+    batch of one or three pairs has an odd row count per view (plain-rows bf3 activations), a batch of two an even one (row-pair
+    layout) -- all three plans must agree."""
+    v = make_view_arrays(3, H, W, seed=4)
     idx = [(0, 1), (2, 1), (1, 2)]
     a = [np.concatenate([v[i][k] for i, _ in idx]) for k in (0, 1)]
     b = [np.concatenate([v[j][k] for _, j in idx]) for k in (0, 1)]
     full = {k: host(t) for k, t in tiny_engine.forward(*to_dev(a[0], b[0], a[1], b[1])).items()}
+    two = {k: host(t) for k, t in tiny_engine.forward(*to_dev(a[0][:2], b[0][:2], a[1][:2], b[1][:2])).items()}
     for n, (i, j) in enumerate(idx):
         one = tiny_engine.forward(*to_dev(v[i][0], v[j][0], v[i][1], v[j][1]))
         for k in full:
             assert rel_err(host(one[k])[0], full[k][n]) < 1e-5, (n, k)
+            if n < 2:
+                assert rel_err(host(one[k])[0], two[k][n]) < 1e-5, (n, k)
 
 
 def test_vitl_config1_vs_reference_golden(vitl_engine):

@@ -32,7 +32,7 @@ def main(src, dst):
     f = collect(f"{src}/fetch/f_counter_collection.csv", "FETCH_SIZE")
     w = collect(f"{src}/write/w_counter_collection.csv", "WRITE_SIZE")
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (each with --kernel-trace only) over "
-                   "`python bench.py --no-cpu-baseline --steps 2 --warmup 1 --align-iters 10 --no-cache-run` (12 pairs/step, 512x384). "
+                   "`python bench.py --no-cpu-baseline --steps 2 --warmup 1 --align-iters 10 --no-cache-run` (the bench's default 42 pairs/step, 512x384). "
                    "Counters are KiB. gfx950 correction (MI355X_MICROARCH.md, HBM): read bytes = 2 * FETCH_SIZE * 1024 for wide "
                    "coalesced reads; WRITE_SIZE exact. Infinity-Cache hits are counted: fabric traffic, an upper bound on HBM traffic.",
            "kernels": {}}
