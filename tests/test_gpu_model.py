@@ -100,6 +100,16 @@ def test_vitl_512x384_vs_oracle(vitl_engine):
         assert rel_err(host(r[k]), ref[k]) < TOL, k
 
 
+def test_vitl_288x512_vs_oracle(vitl_engine):
+    """BASELINE config-3 resolution (512x288, N = 576 tokens, 32 x 18 grid): one pair against the numpy oracle."""
+    from oracle import model_np as O
+    v = make_view_arrays(2, 288, 512, seed=3)
+    r = vitl_engine.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
+    ref = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        assert rel_err(host(r[k]), ref[k]) < TOL, k
+
+
 def test_shape_errors(tiny_engine):
     z = lambda *s: torch.zeros(*s, device="cuda")
     with pytest.raises(RuntimeError, match="multiple of patch size"):
