@@ -364,6 +364,9 @@ int main(int argc, char** argv) {
         };
         upload(2, 2);
         RUN("256x128 16w m16 NS2 RB2", 256, 128, 32, 4, 4, 2, 2 | 64);
+        RUN("256x128 16w m16 NS2 RB2 setprio", 256, 128, 32, 4, 4, 2, 2 | 64 | 1);
+        RUN("256x128 8w(4x2) m16 NS2 RB2", 256, 128, 32, 4, 2, 2, 2 | 64);
+        RUN("256x128 8w(2x4) m16 NS2 RB2", 256, 128, 32, 2, 4, 2, 2 | 64);
         upload(16, 16);
         RUN("256x128 16w m16 NS2 RB16", 256, 128, 32, 4, 4, 2, 2 | 128);
         RUN("128x64 4w m16 NS2 RB16", 128, 64, 32, 2, 2, 2, 2 | 128);
