@@ -39,6 +39,7 @@ def parse(argv=None):
     ap.add_argument("--min-conf-thr", type=float, default=3.0)
     ap.add_argument("--gt-depth", default=None, help="folder of per-frame ground-truth depth .npy (same order) -> AbsRel etc.")
     ap.add_argument("--depth-max", type=float, default=70.0)
+    ap.add_argument("--gt-traj", default=None, help="ground-truth camera trajectory, TUM file `t x y z qx qy qz qw` (same frames) -> ATE / RPE")
     ap.add_argument("--quiet", action="store_true")
     return ap.parse_args(argv)
 
@@ -83,7 +84,17 @@ def main(argv=None):
         metrics = evaluate_depth(np.stack(depths), gt, depth_max=a.depth_max, mode="lad")
         if verbose:
             print("depth metrics (LAD scale+shift):", {k: round(v, 5) if isinstance(v, float) else v for k, v in metrics.items()})
-    return dict(n_frames=len(depths), out=a.out, metrics=metrics)
+    pose = None
+    if a.gt_traj:
+        from .pose_metrics import eval_metrics, read_pred_traj, read_tum_file
+        gt = read_tum_file(a.gt_traj)
+        gt = [gt[0][a.start:a.start + len(depths)], gt[1][a.start:a.start + len(depths)]]
+        ate, rpe_t, rpe_r = eval_metrics(read_pred_traj(os.path.join(a.out, "pred_traj.txt")), gt, seq=os.path.basename(a.images.rstrip("/")),
+                                         filename=os.path.join(a.out, "eval_metric.txt"))
+        pose = dict(ate=ate, rpe_trans=rpe_t, rpe_rot=rpe_r)
+        if verbose:
+            print("pose metrics (Sim(3)-aligned):", {k: round(v, 5) for k, v in pose.items()})
+    return dict(n_frames=len(depths), out=a.out, metrics=metrics, pose_metrics=pose)
 
 
 if __name__ == "__main__":

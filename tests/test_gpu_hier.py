@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _scene(N, H, W):
+def _scene(N, H, W, curve=0.0):
     f = 1.2 * max(H, W)
     xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     rays = np.stack([(xs - W / 2) / f, (ys - H / 2) / f, np.ones_like(xs)], -1)
@@ -22,7 +22,7 @@ def _scene(N, H, W):
     for n in range(N):
         a = 0.05 * n
         R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
-        t = np.array([0.2 * n, 0.03 * n, 0.01 * n])
+        t = np.array([0.2 * n, 0.03 * n + curve * n * n, 0.01 * n])       # curve != 0: camera centres not collinear (pose metrics)
         d = 3 + 0.8 * np.sin(xs / W * 5 + 0.3 * n) * np.cos(ys / H * 4)
         cams.append((R, t))
         world.append((rays * d[..., None]) @ R.T + t)
@@ -115,11 +115,17 @@ def test_run_clip_end_to_end_from_files(tmp_path, monkeypatch):
     frames, gt = tmp_path / "frames", tmp_path / "gt"
     frames.mkdir(); gt.mkdir()
     N, H, W = 4, 48, 64
-    cams, world, f = _scene(N, H, W)
+    cams, world, f = _scene(N, H, W, curve=0.03)
     for i in range(N):
         PIL.Image.fromarray(rng.randint(0, 256, (60, 80, 3)).astype(np.uint8)).save(frames / f"f_{i:03d}.png")
         np.savez(frames / f"f_{i:03d}_pred_depth_depthpro.npz", depth=(1 + rng.rand(60, 80)).astype(np.float32), focallength_px=np.float32(70.0))
         np.save(gt / f"f_{i:03d}.npy", (((world[i] - cams[i][1]) @ cams[i][0])[..., 2]).astype(np.float32))     # true depth
+    from scipy.spatial.transform import Rotation
+    with open(tmp_path / "gt_traj.txt", "w") as fh:                          # TUM convention: t x y z qx qy qz qw (camera-to-world)
+        fh.write("# timestamp tx ty tz qx qy qz qw\n")
+        for i, (R, t) in enumerate(cams):
+            q = Rotation.from_matrix(R).as_quat()
+            fh.write(f"{i} {t[0]} {t[1]} {t[2]} {q[0]} {q[1]} {q[2]} {q[3]}\n")
     kw = _parse_model_string(model_string(TINY))
     ckpt = str(tmp_path / "tiny.pth")
     save_checkpoint(ckpt, AsymmetricCroCo3DStereo(**{**kw, "landscape_only": False}))
@@ -141,11 +147,16 @@ def test_run_clip_end_to_end_from_files(tmp_path, monkeypatch):
     monkeypatch.setattr(inf_mod, "inference", inference_then_consistent_geometry)
     torch.manual_seed(0)
     res = run_clip.main(["--images", str(frames), "--weights", ckpt, "--out", str(tmp_path / "out"), "--size", "64", "--niter", "30",
-                         "--scene-graph", "complete", "--min-conf-thr", "1.5", "--gt-depth", str(gt), "--quiet"])
+                         "--scene-graph", "complete", "--min-conf-thr", "1.5", "--gt-depth", str(gt), "--gt-traj", str(tmp_path / "gt_traj.txt"),
+                         "--quiet"])
     assert seen["shape"] == (12, H, W, 3)
     assert res["n_frames"] == N and res["metrics"]["n_valid"] == N * H * W
     assert res["metrics"]["abs_rel"] < 0.02 and res["metrics"]["d1"] > 0.99          # aligned depth = true depth up to scale/shift
+    # the recovered trajectory is the true one up to a similarity (ATE / RPE after Sim(3) alignment, scene extent ~ 1)
+    pm = res["pose_metrics"]
+    assert pm["ate"] < 0.02 and pm["rpe_trans"] < 0.03 and pm["rpe_rot"] < 1.0, pm
     out = tmp_path / "out"
+    assert "rmse" in (out / "eval_metric.txt").read_text()
     assert len((out / "pred_traj.txt").read_text().splitlines()) == N
     assert sorted(p.name for p in out.glob("frame_*.npy")) == [f"frame_{i:04d}.npy" for i in range(N)]
     d = np.load(out / "frame_0002.npy")

@@ -195,3 +195,57 @@ def test_flow_geometry_matches_reference():
     occ = OccMask(th=3.0)
     assert torch.equal(occ(t("f12"), t("f21")), t("occ_a")) and torch.equal(occ(t("f12"), t("f21c")), t("occ_b"))
     assert 0 < int(t("occ_b").sum()) < t("occ_b").numel()
+
+
+# ------------------------------------------------------------------------------------------------- pose metrics (vo_eval.py:185-269)
+def _rand_traj(n, seed=0):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    xyz = np.cumsum(rng.standard_normal((n, 3)) * 0.3, axis=0)
+    return np.concatenate([xyz, q], 1), np.arange(n, dtype=np.float64)[:, None]
+
+
+def test_pose_metrics_defining_properties(tmp_path):
+    """ATE / RPE as evo defines them (PARITY UNPINNED: evo is not available): zero for identical trajectories, invariant to a
+    similarity transform of the estimate, and equal to closed-form values for constructed errors."""
+    from align3r_amd.tool import pose_metrics as pm
+    gt, ts = _rand_traj(30, seed=1)
+    ate, rt, rr = pm.eval_metrics([gt.copy(), ts], [gt, ts], seq="s", filename=str(tmp_path / "m.txt"))
+    assert ate < 1e-9 and rt < 1e-9 and rr < 1e-5
+    assert "rmse" in open(tmp_path / "m.txt").read()
+    # a Sim(3)-transformed copy of the truth is a perfect estimate (align=True, correct_scale=True)
+    T = pm.tum_to_matrices(gt)
+    ang = 0.7
+    R0 = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    S = np.eye(4); S[:3, :3] = R0; S[:3, 3] = [1.0, -2.0, 0.5]
+    est = S @ T
+    est[:, :3, 3] = 2.5 * (T[:, :3, 3] @ R0.T) + S[:3, 3]
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(est[:, :3, :3]).as_quat()          # xyzw
+    est_tum = np.concatenate([est[:, :3, 3], q[:, [3, 0, 1, 2]]], 1)
+    ate, rt, rr = pm.eval_metrics([est_tum, ts], [gt, ts])
+    assert ate < 1e-8 and rt < 1e-8 and rr < 1e-4
+    # Umeyama recovers the similarity
+    R, t, c = pm.umeyama_alignment(est[:, :3, 3].T, T[:, :3, 3].T, True)
+    assert abs(c - 1 / 2.5) < 1e-9 and np.allclose(R, R0.T, atol=1e-9)
+    # constructed errors on an unrotated planar path (a straight line is degenerate for Umeyama, as in evo): turning only the odd
+    # frames by an angle about z leaves the camera centres (ATE) alone and makes every consecutive relative rotation that angle
+    n = 20
+    line = np.zeros((n, 7)); line[:, 0] = np.arange(n); line[:, 1] = 3 * np.sin(np.arange(n) / 3.0); line[:, 3] = 1.0
+    tsl = np.arange(n, dtype=np.float64)[:, None]
+    turned = line.copy()
+    half = np.deg2rad(6.0) / 2
+    turned[1::2, 3], turned[1::2, 6] = np.cos(half), np.sin(half)
+    ate, rt, rr = pm.eval_metrics([turned, tsl], [line, tsl])
+    assert ate < 1e-9 and abs(rr - 6.0) < 1e-6
+    # a sideways offset d on the odd frames: relative translations are off by d for every pair; ATE follows from the alignment
+    off = line.copy(); off[1::2, 1] += 0.2
+    ate, rt, rr = pm.eval_metrics([off, tsl], [line, tsl])
+    ref, est_al = pm.tum_to_matrices(line), pm.align_trajectory(pm.tum_to_matrices(off), pm.tum_to_matrices(line))[0]
+    assert abs(ate - np.sqrt(np.mean(np.sum((ref[:, :3, 3] - est_al[:, :3, 3]) ** 2, 1)))) < 1e-12 and 0.05 < ate < 0.2
+    assert abs(rt - 0.2) < 0.02 and rr < 0.5
+    with pytest.raises(ValueError, match="Degenerate"):
+        straight = np.zeros((n, 7)); straight[:, 0] = np.arange(n); straight[:, 3] = 1.0
+        pm.eval_metrics([straight.copy(), tsl], [straight, tsl])
+    with pytest.raises(ValueError, match="different lengths"):
+        pm.eval_metrics([gt[:-1], ts[:-1]], [gt, ts])
