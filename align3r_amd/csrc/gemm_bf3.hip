@@ -251,7 +251,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
         }
-        gemm_epilogue16<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
+        static_assert(NS * STAGE >= WM * WN * epi_lds_wave_bytes(WTM) || TN != 2, "the LDS epilogue image fits in the stage ring");
+        if (TN == 2 && epilogue16_lds_ok(g, P)) {                 // wave-uniform
+            __syncthreads();                                       // every wave is done reading the last stage
+            if constexpr (TN == 2)
+                gemm_epilogue16_lds<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane,
+                                                  reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)));
+        } else {
+            gemm_epilogue16<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
+        }
     }
 }
 
@@ -453,6 +461,8 @@ static int launch_bf3_w2h(const GemmArgs& g, hipStream_t st) {
 
 template <int AMODE>
 static int launch_bf3(GemmArgs& g, hipStream_t st) {
+    static const bool direct_epi = getenv("A3R_BF3_DIRECT_EPI") != nullptr;
+    g.direct_epilogue = direct_epi ? 1 : 0;
     const int t = choose_bf3_tile(g.M, g.N, g.groups, AMODE == 0);
     const int bm = kTiles[t].bm, bn = kTiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;

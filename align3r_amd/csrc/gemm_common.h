@@ -24,6 +24,7 @@ struct GemmArgs {
     a3r_epilogue epi;       // pointers inside are ignored (taken from grp[]) except the rope tables
     // implicit conv (AMODE 1): A = x [B, H, W, Cin]
     int cH, cW, cCin, cHo, cWo, cStride;
+    int direct_epilogue;    // A/B switch (env A3R_BF3_DIRECT_EPI): keep the accumulator-layout epilogue instead of the LDS-staged one
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -195,6 +196,172 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, const GroupPt
         else if (ep.epi == A3R_EPI_RELU) gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_RELU, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);
         else gemm_epilogue16_body<TM, TN, FULL, A3R_EPI_NONE, 1>(g, P, acc, m0, n0, wrow0, wcol0, lane);      // (PIXSHUF has no bf3 form)
     }
+}
+
+// ---- the same epilogue staged through LDS (the stage ring is idle by then).  In the accumulator layout a lane holds ONE column
+// of four rows, so the direct form above issues 4-byte loads / stores that touch four 64-byte row segments per instruction -- at
+// K = 1024 the residual loads, fp32 stores and especially the 4-byte bf3 pieces cost 17-26 % of the whole GEMM (tools/bench_epi.py).
+// Here every wave writes its WTM x WTN tile (bias / RoPE / activation applied) into a private LDS image with ds_write_b32, reads it
+// back as float4 of one row per lane, and does the residual loads, fp32 stores and bf3 splits on 16-byte row-contiguous pieces:
+// a wave instruction then covers whole 128-byte lines.  Needs ldc % 4 == 0 and 16-byte aligned y / resid (checked by the caller
+// through epilogue16_lds_ok); PIXSHUF keeps the direct form.  lds: this wave's WTM x EPI_LDS_PITCH floats.
+constexpr int EPI_LDS_PITCH = 36;      // floats per LDS row for WTN = 32 (+4: 16-byte aligned rows that rotate over the banks)
+constexpr int EPI_IMG_PITCH = 208;     // bytes per row of the 32-row bf3 image (13 units)
+// bytes of LDS one wave needs for a WTM-row tile: the fp32 tile or the 32-row bf3 image, whichever is larger
+constexpr int epi_lds_wave_bytes(int wtm) { return wtm * EPI_LDS_PITCH * 4 > 32 * EPI_IMG_PITCH ? wtm * EPI_LDS_PITCH * 4 : 32 * EPI_IMG_PITCH; }
+
+template <int TM, int TN, bool FULL, int EPI, int O3>
+__device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
+                                                         int wrow0, int wcol0, int lane, float* lds) {
+    static_assert(TN == 2, "wave tiles 32 columns wide");
+    constexpr int WTM = TM * 16, WTN = TN * 16, LPR = WTN / 4, RPI = 64 / LPR, ITERS = WTM / RPI;      // lanes per row, rows per pass
+    const a3r_epilogue& ep = g.epi;
+    const int quad = lane >> 4, lcol = lane & 15;
+    const int epi = EPI >= 0 ? EPI : ep.epi;
+    const bool only3 = O3 == 0 ? false : ep.out_bf3 != 0;
+    // value of element e of accumulator (i, j) after bias / RoPE / activation
+    auto value = [&](int i, int j, int e, float bias, float bias_o, bool do_rope, bool rope_x, bool second) {
+        float v = acc[i][j][e] + bias;
+        if (do_rope) {
+            const int row = m0 + wrow0 + i * 16 + quad * 4 + e;
+            const float other = acc[i][j ^ 1][e] + bias_o;
+            const int tok = row % ep.tokens_per_image;
+            const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
+            const int pp = rope_x ? px : py;
+            const float c = ep.rope_cos[pp * 16 + lcol], sn = ep.rope_sin[pp * 16 + lcol];
+            v = second ? v * c + other * sn : v * c - other * sn;
+        }
+        if (epi == A3R_EPI_GELU) v = gelu_erf(v);
+        else if (epi == A3R_EPI_RELU) v = fmaxf(v, 0.f);
+        return v;
+    };
+    if (O3 != 0 && only3) {
+        // ---- bf3 output only: the split planes go to LDS as the final memory image of 32 rows x 32 columns (192 B per row), and
+        // come back one 16-byte unit per lane, consecutive lanes = consecutive units: every store instruction writes 1 KB of
+        // whole cache lines (row pairs are 384 contiguous bytes in the pair layout, rows 192 in the plain one)
+        static_assert(TM % 2 == 0, "halves of 32 rows");
+        constexpr int IMG_PITCH = EPI_IMG_PITCH;                     // 13 units: rows rotate over the LDS banks
+        char* img = reinterpret_cast<char*>(lds);
+        const int pair3 = ep.out_pair;
+        char* out3 = reinterpret_cast<char*>(P.C);
+        const int kcol0 = n0 + wcol0;                                // a multiple of 32: one whole k block of the output rows
+#pragma unroll
+        for (int half = 0; half < TM / 2; half++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int colbase = n0 + wcol0 + j * 16;
+                const int col = colbase + lcol;
+                const bool col_ok = FULL || col < g.N;
+                const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
+                const float bias_o = (epi == A3R_EPI_ROPE && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] : 0.f;
+                const bool do_rope = epi == A3R_EPI_ROPE && colbase < ep.rope_cols;
+                const bool rope_x = (colbase & 32) != 0, second = (colbase & 16) != 0;
+                const int cw = j * 16 + lcol;
+                char* dcol = img + (cw >> 3) * 48 + (cw & 7) * 2;
+#pragma unroll
+                for (int il = 0; il < 2; il++)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int i = half * 2 + il;
+                        const float v0 = value(i, j, e, bias, bias_o, do_rope, rope_x, second);
+                        const float v1 = value(i, j, e + 1, bias, bias_o, do_rope, rope_x, second);
+                        uint32_t p0, p1, p2;
+                        bf3_split2(v0, v1, p0, p1, p2);                // low half: row e, high half: row e + 1
+                        char* d = dcol + (il * 16 + quad * 4 + e) * IMG_PITCH;
+                        *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
+                        *reinterpret_cast<uint16_t*>(d + 16) = (uint16_t)p1;
+                        *reinterpret_cast<uint16_t*>(d + 32) = (uint16_t)p2;
+                        *reinterpret_cast<uint16_t*>(d + IMG_PITCH) = (uint16_t)(p0 >> 16);
+                        *reinterpret_cast<uint16_t*>(d + IMG_PITCH + 16) = (uint16_t)(p1 >> 16);
+                        *reinterpret_cast<uint16_t*>(d + IMG_PITCH + 32) = (uint16_t)(p2 >> 16);
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 6; it++) {                          // 32 rows x 12 units = 6 x 64 lanes
+                const int u = it * 64 + lane, r = u / 12, un = u - r * 12;
+                const int grow = m0 + wrow0 + half * 32 + r;
+                const u32x4 dv = *reinterpret_cast<const u32x4*>(img + r * IMG_PITCH + un * 16);
+                if ((FULL || (grow < g.M && kcol0 + (un / 3) * 8 < g.N)))
+                    *reinterpret_cast<u32x4*>(out3 + bf3_row_offset(grow, g.N, pair3) + bf3_k_offset(kcol0, pair3) + un * 16) = dv;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                       // the reads are done before the next half overwrites the image
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // ---- phase 1: bias, RoPE, activation in the accumulator layout -> LDS
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int colbase = n0 + wcol0 + j * 16;
+        const int col = colbase + lcol;
+        const bool col_ok = FULL || col < g.N;
+        const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
+        const float bias_o = (epi == A3R_EPI_ROPE && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] : 0.f;
+        const bool do_rope = epi == A3R_EPI_ROPE && colbase < ep.rope_cols;
+        const bool rope_x = (colbase & 32) != 0, second = (colbase & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                lds[(i * 16 + quad * 4 + e) * EPI_LDS_PITCH + j * 16 + lcol] = value(i, j, e, bias, bias_o, do_rope, rope_x, second);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes are done (the image is wave-private)
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2: one float4 of one row per lane: residuals, fp32 store, the auxiliary bf3 form
+    char* out3 = O3 == 0 ? nullptr : static_cast<char*>(ep.aux_bf3);
+    const bool relu3 = ep.aux_relu;
+    const int r_in = lane / LPR, c4 = (lane % LPR) * 4;
+    const int gcol = n0 + wcol0 + c4;
+    const bool col_ok = FULL || gcol < g.N;                  // N % 4 == 0 on this path: a float4 is in or out as a whole
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int rl = it * RPI + r_in;
+        const int grow = m0 + wrow0 + rl;
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds + rl * EPI_LDS_PITCH + c4);
+        const bool ok = col_ok && (FULL || grow < g.M);
+        if (!ok) continue;
+        const size_t o = (size_t)grow * g.ldc + gcol;
+        if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) v += *reinterpret_cast<const f32x4*>(P.resid + o);
+        if (epi == A3R_EPI_RESID2) v += *reinterpret_cast<const f32x4*>(P.resid2 + o);
+        *reinterpret_cast<f32x4*>(P.C + o) = v;
+        if (out3) {
+            if (relu3) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            bf3_store4(out3 + bf3_row_offset(grow, g.N, 0), gcol, v, 0);
+        }
+    }
+}
+
+// whether the LDS form applies to this launch (wave-uniform; otherwise the direct form runs)
+__device__ __forceinline__ bool epilogue16_lds_ok(const GemmArgs& g, const GroupPtrs& P) {
+    const a3r_epilogue& ep = g.epi;
+    if (g.direct_epilogue || ep.epi == A3R_EPI_PIXSHUF || (g.ldc & 3) || (g.N & 3)) return false;
+    uintptr_t a = reinterpret_cast<uintptr_t>(P.C);
+    if (ep.epi == A3R_EPI_RESID || ep.epi == A3R_EPI_RESID2) a |= reinterpret_cast<uintptr_t>(P.resid);
+    if (ep.epi == A3R_EPI_RESID2) a |= reinterpret_cast<uintptr_t>(P.resid2);
+    return (a & 15) == 0;
+}
+
+template <int TM, int TN, bool FULL>
+__device__ __forceinline__ void gemm_epilogue16_lds(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
+                                                    int wrow0, int wcol0, int lane, float* lds) {
+    const a3r_epilogue& ep = g.epi;
+    const bool has3 = ep.out_bf3 || ep.aux_bf3;
+#define A3R_EPI_LDS(E, O) gemm_epilogue16_lds_body<TM, TN, FULL, E, O>(g, P, acc, m0, n0, wrow0, wcol0, lane, lds)
+    if (!has3) {
+        if (ep.epi == A3R_EPI_RESID) A3R_EPI_LDS(A3R_EPI_RESID, 0);
+        else if (ep.epi == A3R_EPI_NONE) A3R_EPI_LDS(A3R_EPI_NONE, 0);
+        else A3R_EPI_LDS(-1, 0);
+    } else {
+        if (ep.epi == A3R_EPI_ROPE) A3R_EPI_LDS(A3R_EPI_ROPE, 1);
+        else if (ep.epi == A3R_EPI_GELU) A3R_EPI_LDS(A3R_EPI_GELU, 1);
+        else if (ep.epi == A3R_EPI_RESID) A3R_EPI_LDS(A3R_EPI_RESID, 1);
+        else if (ep.epi == A3R_EPI_RESID2) A3R_EPI_LDS(A3R_EPI_RESID2, 1);
+        else if (ep.epi == A3R_EPI_RELU) A3R_EPI_LDS(A3R_EPI_RELU, 1);
+        else A3R_EPI_LDS(A3R_EPI_NONE, 1);
+    }
+#undef A3R_EPI_LDS
 }
 
 static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who, bool bf3_kernel = false) {
