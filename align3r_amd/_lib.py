@@ -45,7 +45,7 @@ class AlignDesc(C.Structure):
                 ("shifts", c_void), ("im_poses", c_void), ("im_focals", c_void), ("im_pp", c_void),
                 ("adam_pw_poses", c_void), ("adam_depth", c_void), ("adam_small", c_void),
                 ("workspace", c_void), ("workspace_bytes", C.c_size_t), ("loss_history", c_void),
-                ("loss_capacity", C.c_int)]
+                ("loss_capacity", C.c_int), ("train_adaptors", C.c_int), ("adam_pw_adaptors", c_void)]
 
 
 class AlignFlowDesc(C.Structure):
@@ -65,6 +65,7 @@ SIGNATURES = {
     "a3r_prof_enable": (C.c_int, [C.c_int]),
     "a3r_prof_kernel_count": (C.c_int, []),
     "a3r_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "a3r_prof_get_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "a3r_rope2d": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_void]),
     "a3r_layernorm": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
     "a3r_linear": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "a3r_align_set_depth_prior": (C.c_int, [c_void, C.c_float, c_void, c_void, c_void, C.c_size_t, c_void]),
     "a3r_align_step_epoch": (C.c_int, [c_void, C.c_float, C.c_int, c_void]),
     "a3r_align_grad_epoch": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_void]),
+    "a3r_align_grad_full": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "a3r_align_flow_state": (C.c_int, [c_void, c_void]),
     "a3r_align_steps_done": (C.c_int, [c_void]),
     "a3r_align_invalidate": (C.c_int, [c_void]),
@@ -167,5 +169,7 @@ def prof_report():
     for k in range(lib.a3r_prof_kernel_count()):
         name, n, ms, work = C.c_char_p(), C.c_long(), C.c_double(), C.c_double()
         check(lib.a3r_prof_get(k, C.byref(name), C.byref(n), C.byref(ms), C.byref(work)))
-        out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, work=work.value))
+        nbytes = C.c_double()
+        check(lib.a3r_prof_get_bytes(k, C.byref(nbytes)))
+        out.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, work=work.value, bytes=nbytes.value))
     return out

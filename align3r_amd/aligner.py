@@ -52,7 +52,7 @@ def schedule_lr(schedule, t, lr, lr_min):
 class AlignEngine:
     def __init__(self, ei, ej, pred_i, pred_j, w_i, w_j, imshapes, mono=None, base_scale=0.5, pw_break=20.0,
                  focal_break=20.0, norm_pw_scale=True, dist="l1", train_poses=True, train_focals=True, train_pp=False,
-                 device="cuda:0", loss_capacity=4096, shared_focal=False, temporal_smoothing_weight=0.0,
+                 train_adaptors=False, device="cuda:0", loss_capacity=4096, shared_focal=False, temporal_smoothing_weight=0.0,
                  translation_weight=0.1, flow=None):
         """flow (cloud_opt_flow variant): dict(flow_ij [E,2,P], flow_ji [E,2,P], dyn [N,P] bool, weight, thre, start_epoch,
         num_total_iter, pxl_thre) -- the optical-flow fields and dynamic masks are inputs (optimizer.py:104-116)."""
@@ -77,7 +77,7 @@ class AlignEngine:
         self.use_mono = mono is not None
         self.mono = f32(mono).reshape(N, P) if self.use_mono else None
         self.flags = dict(norm_pw_scale=bool(norm_pw_scale), dist_l2=(dist == "l2"), train_poses=bool(train_poses),
-                          train_focals=bool(train_focals), train_pp=bool(train_pp))
+                          train_focals=bool(train_focals), train_pp=bool(train_pp), train_adaptors=bool(train_adaptors))
         self.base_scale, self.pw_break, self.focal_break = base_scale, pw_break, focal_break
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         self.shared_focal = bool(shared_focal)
@@ -96,7 +96,7 @@ class AlignEngine:
                            im_focals=z(1 if self.shared_focal else N), im_pp=z(N, 2))
         self.flow_workspace = (torch.empty(int(self.lib.a3r_align_flow_workspace_bytes(E, N, P)), dtype=torch.uint8, device=dev)
                                if self.flow_variant else None)
-        self.adam = dict(pw_poses=z(2, E, 8), depth=z(2, N, P), small=z(2, N, 16))
+        self.adam = dict(pw_poses=z(2, E, 8), depth=z(2, N, P), small=z(2, N, 16), pw_adaptors=z(2, E, 2))
         self.loss_capacity = loss_capacity
         self.loss_history = z(loss_capacity)
         self.total_area_i = float(sum(int(self.imarea[i]) for i in self.ei))
@@ -107,13 +107,16 @@ class AlignEngine:
 
     def _create(self):
         if self.handle:
-            self.lib.a3r_align_destroy(self.handle)
+            h_old, self.handle = self.handle, None          # never leave a destroyed handle behind if the re-creation below fails
+            self.lib.a3r_align_destroy(h_old)
         d = AlignDesc()
         d.E, d.N, d.P = self.E, self.N, self.P
         d.use_mono = int(self.use_mono)
         d.norm_pw_scale = int(self.flags["norm_pw_scale"]); d.dist_l2 = int(self.flags["dist_l2"])
         d.train_poses = int(self.flags["train_poses"]); d.train_focals = int(self.flags["train_focals"])
         d.train_pp = int(self.flags["train_pp"])
+        d.train_adaptors = int(self.flags.get("train_adaptors", False))
+        d.adam_pw_adaptors = self.adam["pw_adaptors"].data_ptr()
         d.base_scale, d.pw_break, d.focal_break = self.base_scale, self.pw_break, self.focal_break
         d.total_area_i, d.total_area_j = self.total_area_i, self.total_area_j
         d.ei_host, d.ej_host = self.ei.ctypes.data, self.ej.ctypes.data
@@ -205,6 +208,8 @@ class AlignEngine:
 
     def trainable(self):
         t = ["pw_poses", "depth"]
+        if self.flags.get("train_adaptors"):
+            t.append("pw_adaptors")
         if self.use_mono:
             t.append("shifts")
         if self.flags["train_poses"]:
@@ -228,14 +233,15 @@ class AlignEngine:
 
     def loss_grad(self, epoch=9999):
         g_pw = torch.zeros_like(self.params["pw_poses"])
+        g_ad = torch.zeros_like(self.params["pw_adaptors"])
         g_depth = torch.zeros_like(self.params["depth"])
         g_small = torch.zeros(self.N, 16, device=self.device)
         loss = torch.zeros(1, device=self.device)
         with torch.cuda.device(self.device):
-            check(self.lib.a3r_align_grad_epoch(self.handle, int(epoch), ptr(g_pw), ptr(g_depth), ptr(g_small), ptr(loss),
-                                                stream_ptr()), "a3r_align_grad")
+            check(self.lib.a3r_align_grad_full(self.handle, int(epoch), ptr(g_pw), ptr(g_ad), ptr(g_depth), ptr(g_small), ptr(loss),
+                                               stream_ptr()), "a3r_align_grad")
         g_f = g_small[:, 7].sum().reshape(1) if self.shared_focal else g_small[:, 7]
-        g = dict(pw_poses=g_pw, depth=g_depth, im_poses=g_small[:, 0:7], im_focals=g_f, im_pp=g_small[:, 8:10],
+        g = dict(pw_poses=g_pw, pw_adaptors=g_ad, depth=g_depth, im_poses=g_small[:, 0:7], im_focals=g_f, im_pp=g_small[:, 8:10],
                  shifts=g_small[:, 10])
         return float(loss.item()), {k: g[k] for k in self.trainable()}
 

@@ -29,14 +29,14 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.9f, ADAM_EPS = 1e-8f;  // base_opt.p
 
 struct AlignDev {
     int E, N, P, nchunks;
-    int norm_pw_scale, train_poses, train_focals, train_pp;
+    int norm_pw_scale, train_poses, train_focals, train_pp, train_adaptors;
     float base_scale, pw_break, focal_break;
     float inv_area_i, inv_area_j;
     const float *pred_i, *pred_j, *w_i, *w_j, *mono, *pp0;
     float *pw_poses, *pw_adaptors, *depth, *shifts, *im_poses, *im_focals, *im_pp;
-    float *adam_pw_poses, *adam_depth, *adam_small;
+    float *adam_pw_poses, *adam_depth, *adam_small, *adam_pw_adaptors;
     // workspace
-    float *edge_xf, *img_xf, *partE, *partN, *gE, *gN, *lossE;
+    float *edge_xf, *img_xf, *partE, *partN, *gE, *gN, *lossE, *gA;
     const int *inc_ptr, *inc, *slot_of, *imw, *imarea;
     float* loss_history;
     // cloud_opt_flow extras (a3r_align_set_flow); all zero / null for the plain cloud_opt aligner
@@ -747,6 +747,18 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
                 for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
                 for (int k = 0; k < 3; k++) g[4 + k] = (float)(-sc * s[9 + k] * signed_expm1_grad(p[4 + k]));
                 g[7] = (float)(dLds * sc);   // S_e * s_e; the mean coupling is applied in finalize B
+                // pw_adaptors (base_opt.py:177-182): aligned = s R diag(a) X + s T with a = exp(adapt / pw_break),
+                // adapt = (p0, p0, p1) [- its mean when norm_pw_scale].  dL/da_c = - sum_r s R_rc (sum g_r X_c).
+                double ga[3], gmean = 0.0;
+                for (int c = 0; c < 3; c++) {
+                    double t = 0.0;
+                    for (int r = 0; r < 3; r++) t -= sc * (double)R[r * 3 + c] * s[r * 3 + c];
+                    ga[c] = t * a[c] / d.pw_break;                   // w.r.t. the (centred) exponent
+                    gmean += ga[c];
+                }
+                if (d.norm_pw_scale) { gmean /= 3.0; for (int c = 0; c < 3; c++) ga[c] -= gmean; }
+                d.gA[e * 2 + 0] = (float)(ga[0] + ga[1]);
+                d.gA[e * 2 + 1] = (float)ga[2];
             }
         }
     } else {
@@ -821,7 +833,7 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
 // MODE 0: loss only -> loss_out; 1: gradients -> g_pw / g_small / loss_out; 2: update.
 template <int MODE>
 __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamArgs ad, float* g_pw, float* g_small,
-                                                               float* loss_out) {
+                                                               float* loss_out, float* g_adapt) {
     __shared__ float sh[TPB];
     __shared__ double shd[2][4];
     const int tid = threadIdx.x;
@@ -857,6 +869,16 @@ __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamA
             float m = d.adam_pw_poses[i], v = d.adam_pw_poses[d.E * 8 + i], p = d.pw_poses[i];
             adam_update(p, g, m, v, ad);
             d.pw_poses[i] = p; d.adam_pw_poses[i] = m; d.adam_pw_poses[d.E * 8 + i] = v;
+        }
+    }
+    for (int i = tid; i < d.E * 2; i += TPB) {
+        const float g = d.gA[i];
+        if (MODE == 1) {
+            if (g_adapt) g_adapt[i] = g;
+        } else if (d.train_adaptors) {
+            float m = d.adam_pw_adaptors[i], v = d.adam_pw_adaptors[d.E * 2 + i], p = d.pw_adaptors[i];
+            adam_update(p, g, m, v, ad);
+            d.pw_adaptors[i] = p; d.adam_pw_adaptors[i] = m; d.adam_pw_adaptors[d.E * 2 + i] = v;
         }
     }
     for (int i = tid; i < d.N * 16; i += TPB) {
@@ -916,7 +938,7 @@ static void refresh_if_dirty(a3r_align_s* a, hipStream_t st) {
     }
 }
 
-static size_t ws_layout(int E, int N, int P, size_t* off /*[12]*/) {
+static size_t ws_layout(int E, int N, int P, size_t* off /*[13]*/) {
     const int nch = (P + CHUNK - 1) / CHUNK;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -932,11 +954,12 @@ static size_t ws_layout(int E, int N, int P, size_t* off /*[12]*/) {
     off[9] = take((size_t)2 * E * 4);               // slot_of
     off[10] = take((size_t)N * 4);                  // imw
     off[11] = take((size_t)N * 4);                  // imarea
+    off[12] = take((size_t)E * 2 * 4);              // gA
     return o;
 }
 
 extern "C" size_t a3r_align_workspace_bytes(int E, int N, int P) {
-    size_t off[12];
+    size_t off[13];
     return ws_layout(E, N, P, off);
 }
 
@@ -949,8 +972,9 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     A3R_CHECK_ARG(!s->use_mono || (s->mono && s->shifts), "a3r_align_create: use_mono needs mono and shifts");
     A3R_CHECK_ARG(s->adam_pw_poses && s->adam_depth && s->adam_small, "a3r_align_create: missing Adam state");
     A3R_CHECK_ARG(s->loss_history && s->loss_capacity > 0, "a3r_align_create: missing loss_history");
-    size_t off[12];
+    size_t off[13];
     const size_t need = ws_layout(s->E, s->N, s->P, off);
+    A3R_CHECK_ARG(!s->train_adaptors || s->adam_pw_adaptors, "a3r_align_create: train_adaptors needs adam_pw_adaptors");
     A3R_CHECK_ARG(s->workspace && s->workspace_bytes >= need, "a3r_align_create: workspace too small (%zu < %zu)",
                   s->workspace_bytes, need);
     // edge indices must be dense 0..N-1 (base_opt.py:164-167)
@@ -991,7 +1015,7 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     AlignDev& d = a->d;
     d.E = s->E; d.N = s->N; d.P = s->P; d.nchunks = (s->P + CHUNK - 1) / CHUNK;
     d.norm_pw_scale = s->norm_pw_scale; d.train_poses = s->train_poses; d.train_focals = s->train_focals;
-    d.train_pp = s->train_pp;
+    d.train_pp = s->train_pp; d.train_adaptors = s->train_adaptors; d.adam_pw_adaptors = s->adam_pw_adaptors;
     d.base_scale = s->base_scale; d.pw_break = s->pw_break; d.focal_break = s->focal_break;
     d.inv_area_i = (float)(1.0 / s->total_area_i); d.inv_area_j = (float)(1.0 / s->total_area_j);
     d.pred_i = s->pred_i; d.pred_j = s->pred_j; d.w_i = s->w_i; d.w_j = s->w_j;
@@ -1002,6 +1026,7 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     d.edge_xf = (float*)(ws + off[0]); d.img_xf = (float*)(ws + off[1]);
     d.partE = (float*)(ws + off[2]); d.partN = (float*)(ws + off[3]);
     d.gE = (float*)(ws + off[4]); d.gN = (float*)(ws + off[5]); d.lossE = (float*)(ws + off[6]);
+    d.gA = (float*)(ws + off[12]);
     d.inc_ptr = (const int*)(ws + off[7]); d.inc = (const int*)(ws + off[8]); d.slot_of = (const int*)(ws + off[9]);
     d.imw = (const int*)(ws + off[10]); d.imarea = (const int*)(ws + off[11]);
     d.loss_history = s->loss_history;
@@ -1146,7 +1171,7 @@ extern "C" int a3r_align_step_epoch(a3r_align_t a, float lr, int epoch, void* st
     {
         ProfScope prof(PK_ALIGN_SMALL, 0.0, st);
         hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
-        hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, nullptr, nullptr);
     }
     A3R_LAUNCH_CHECK();
     a->steps++;
@@ -1165,13 +1190,13 @@ extern "C" int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream) {
     launch_flow(a, 1 << 30, st);                                       // net() defaults to epoch=9999: flow term active
     launch_main<0>(a, ad, nullptr, st);
     hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 1);
-    hipLaunchKernelGGL((align_finalize_b_kernel<0>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, loss_dev);
+    hipLaunchKernelGGL((align_finalize_b_kernel<0>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, loss_dev, nullptr);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
 
-extern "C" int a3r_align_grad_epoch(a3r_align_t a, int epoch, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,
-                                    void* stream) {
+extern "C" int a3r_align_grad_full(a3r_align_t a, int epoch, float* g_pw_poses, float* g_pw_adaptors, float* g_depth, float* g_small,
+                                   float* loss_dev, void* stream) {
     A3R_CHECK_ARG(a && g_pw_poses && g_depth && g_small && loss_dev, "a3r_align_grad: null argument");
     hipStream_t st = as_stream(stream);
     AdamArgs ad = {};
@@ -1179,9 +1204,14 @@ extern "C" int a3r_align_grad_epoch(a3r_align_t a, int epoch, float* g_pw_poses,
     launch_flow(a, epoch, st);
     launch_main<1>(a, ad, g_depth, st);
     hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
-    hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, g_pw_poses, g_small, loss_dev);
+    hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, g_pw_poses, g_small, loss_dev, g_pw_adaptors);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
+}
+
+extern "C" int a3r_align_grad_epoch(a3r_align_t a, int epoch, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,
+                                    void* stream) {
+    return a3r_align_grad_full(a, epoch, g_pw_poses, nullptr, g_depth, g_small, loss_dev, stream);
 }
 
 extern "C" int a3r_align_grad(a3r_align_t a, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev,

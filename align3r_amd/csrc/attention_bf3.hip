@@ -261,12 +261,11 @@ extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ld
     A3R_CHECK_ARG(!out_pair || ldo % 32 == 0, "a3r_attention_bf3: the row-pair output layout needs ldo %% 32 == 0");
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q3) | reinterpret_cast<uintptr_t>(k3) | reinterpret_cast<uintptr_t>(v3) |
                     reinterpret_cast<uintptr_t>(o3)) & 15) == 0, "a3r_attention_bf3: pointers must be 16-byte aligned");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
-        attr_done = true;
     }
     Attn3Args a = {static_cast<const char*>(q3), static_cast<const char*>(k3), static_cast<const char*>(v3), static_cast<char*>(o3),
                    (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk, ldo, out_pair ? 1 : 0};

@@ -27,8 +27,8 @@ extern "C" int a3r_device_count(void) {
 #include <deque>
 #include <vector>
 namespace a3r {
-struct ProfRec { int kernel; double work; hipEvent_t e0, e1; };
-struct ProfTotal { long launches = 0; double ms = 0, work = 0; };
+struct ProfRec { int kernel; double work, bytes; hipEvent_t e0, e1; };
+struct ProfTotal { long launches = 0; double ms = 0, work = 0, bytes = 0; };
 static bool g_prof_on = false;
 static std::deque<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -47,7 +47,7 @@ static hipEvent_t get_event() {
 static void fold(const ProfRec& r) {
     float t = 0;
     if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
-        g_tot[r.kernel].launches++; g_tot[r.kernel].ms += t; g_tot[r.kernel].work += r.work;
+        g_tot[r.kernel].launches++; g_tot[r.kernel].ms += t; g_tot[r.kernel].work += r.work; g_tot[r.kernel].bytes += r.bytes;
     }
     g_pool.push_back(r.e0); g_pool.push_back(r.e1);
 }
@@ -61,9 +61,9 @@ static void drain(bool wait) {
     }
 }
 bool prof_enabled() { return g_prof_on; }
-void prof_begin(int kernel, double work, hipStream_t st) {
+void prof_begin(int kernel, double work, hipStream_t st, double bytes) {
     if (g_recs.size() >= 128) drain(false);
-    ProfRec r{kernel, work, get_event(), get_event()};
+    ProfRec r{kernel, work, bytes, get_event(), get_event()};
     (void)hipEventRecord(r.e0, st);
     g_recs.push_back(r);
 }
@@ -86,5 +86,12 @@ extern "C" int a3r_prof_get(int kernel, const char** name, long* launches, doubl
     drain(true);
     *name = g_names[kernel];
     *launches = g_tot[kernel].launches; *total_ms = g_tot[kernel].ms; *total_work = g_tot[kernel].work;
+    return A3R_OK;
+}
+extern "C" int a3r_prof_get_bytes(int kernel, double* total_bytes) {
+    using namespace a3r;
+    A3R_CHECK_ARG(kernel >= 0 && kernel < PK_COUNT && total_bytes, "a3r_prof_get_bytes: bad argument");
+    drain(true);
+    *total_bytes = g_tot[kernel].bytes;
     return A3R_OK;
 }

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <atomic>
 #include "../../include/a3r.h"
 
 namespace a3r {
@@ -39,12 +40,29 @@ void set_error(const char* fmt, ...);
 // ---- optional per-kernel timing with HIP events on the launch stream (a3r_prof_* in include/a3r.h)
 enum ProfKernel { PK_LINEAR = 0, PK_CONV, PK_ATTENTION, PK_LAYERNORM, PK_ELEMENTWISE, PK_ALIGN_MAIN, PK_ALIGN_SMALL, PK_LINEAR_BF3, PK_SPLIT, PK_CONV_BF3, PK_ATTENTION_BF3, PK_COUNT };
 bool prof_enabled();
-void prof_begin(int kernel, double work, hipStream_t st);
+void prof_begin(int kernel, double work, hipStream_t st, double bytes = 0);
 void prof_end(hipStream_t st);
 struct ProfScope {
     hipStream_t st; bool on;
-    ProfScope(int kernel, double work, hipStream_t s) : st(s), on(prof_enabled()) { if (on) prof_begin(kernel, work, st); }
+    // work: algorithmic FLOP (MFMA kernels) or bytes (HBM-bound kernels); bytes: algorithmic operand + result bytes of an MFMA kernel
+    // (each operand read once, each result written once), so that PMC traffic / algorithmic bytes can be read off the bench line
+    ProfScope(int kernel, double work, hipStream_t s, double bytes = 0) : st(s), on(prof_enabled()) { if (on) prof_begin(kernel, work, st, bytes); }
     ~ProfScope() { if (on) prof_end(st); }
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the CURRENT DEVICE's function object: a process that builds engines
+// on several GPUs must opt in on each.  One atomic bit per device and call site; racing first launches on one device both set
+// the (idempotent) attribute.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    // true when the caller still has to run the per-device setup (and marks it done)
+    bool first(int* dev_out = nullptr) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;     // unknown device: always set
+        if (dev_out) *dev_out = dev;
+        const unsigned long long bit = 1ull << dev;
+        return !(done.fetch_or(bit, std::memory_order_relaxed) & bit);
+    }
 };
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -435,10 +435,9 @@ static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_bf3_kernel<AMODE, BM, BN, BK, WM, WN, NS, MF, FULL, NP>;
     constexpr int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(WM * WN * 64), lds, st, g);
     A3R_LAUNCH_CHECK();
@@ -449,10 +448,9 @@ template <bool FULL, int NP>
 static int launch_bf3_w2h(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_bf3_w2h_kernel<FULL, NP>;
     constexpr int lds = 2 * 256 * 192 + 2 * 128 * 192;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(512), lds, st, g);
     A3R_LAUNCH_CHECK();
@@ -469,7 +467,13 @@ static int launch_bf3(GemmArgs& g, hipStream_t st) {
     g.tiles_n = (g.N + bn - 1) / bn;
     g.tiles_per_group = g.tiles_m * g.tiles_n;
     const bool full = g.M % bm == 0 && g.N % bn == 0;
-    ProfScope prof(AMODE == 0 ? PK_LINEAR_BF3 : PK_CONV_BF3, 2.0 * g.M * g.N * g.K * g.groups, st);
+    // algorithmic bytes: A once (linear: M K 6; conv: the input map B H W Cin 6), W once, results / residuals once
+    const double mn = (double)g.M * g.N;
+    const double a_bytes = AMODE == 0 ? 6.0 * g.M * g.K : 6.0 * (g.M / (g.cHo * g.cWo)) * g.cH * g.cW * g.cCin;
+    const double c_bytes = mn * ((g.epi.out_bf3 ? 6.0 : 4.0) + (g.epi.aux_bf3 ? 6.0 : 0.0) +
+                                 (g.epi.epi == A3R_EPI_RESID ? 4.0 : g.epi.epi == A3R_EPI_RESID2 ? 8.0 : 0.0));
+    ProfScope prof(AMODE == 0 ? PK_LINEAR_BF3 : PK_CONV_BF3, 2.0 * g.M * g.N * g.K * g.groups, st,
+                   g.groups * (a_bytes + 6.0 * g.N * g.K + c_bytes));
 #define A3R_BF3_DISPATCH(NPV)                                                                                                   \
     do {                                                                                                                        \
         if (t == 0) return full ? launch_bf3_variant<AMODE, 256, 128, 32, 4, 4, 2, 16, true, NPV>(g, st)                        \

@@ -97,15 +97,26 @@ class PointCloudOptimizer:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = device
         E, P = len(self.edges), self.max_area
+        state = self._current_state()          # a repeated .to() keeps the parameter values (nn.Module.to semantics)
         w_i = self.conf_trf(self._conf_i).reshape(E, P)
         w_j = self.conf_trf(self._conf_j).reshape(E, P)
         self.engine = AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i.reshape(E, P, 3),
                                   self._pred_j.reshape(E, P, 3), w_i, w_j, self.imshapes, mono=self.mono_depths,
                                   base_scale=self.base_scale, pw_break=self.pw_break, focal_break=self.focal_break,
                                   norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device, **self._flags)
-        self.engine.set_params(**self._init)
-        self._pred_i = self._pred_j = self._conf_i = self._conf_j = None   # the engine holds the device copies
+        self.engine.set_params(**(state or self._init))
+        # keep handles on the engine's device tensors instead of the (possibly host) originals: no second copy stays alive, and
+        # .to() can be called again like nn.Module.to (the confidences are re-derived from the raw host copies)
+        self._pred_i, self._pred_j = self.engine.pred_i, self.engine.pred_j
+        self._conf_i, self._conf_j = self._raw_conf_i, self._raw_conf_j
         return self
+
+    def _current_state(self):
+        """Parameter values of the live engine (host copies), or None before the first .to()."""
+        if self.engine is None:
+            return None
+        keys = ['pw_poses', 'depth', 'im_poses', 'im_focals', 'im_pp', 'pw_adaptors'] + (['shifts'] if self.if_use_mono else [])
+        return {k: self.engine.params[k].detach().cpu().clone() for k in keys}
 
     def _need_engine(self):
         if self.engine is None:

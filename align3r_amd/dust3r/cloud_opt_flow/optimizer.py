@@ -111,6 +111,7 @@ class PointCloudOptimizer(_Base):
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = device
         E, P = len(self.edges), self.max_area
+        state = self._current_state()          # a repeated .to() keeps the parameter values (nn.Module.to semantics)
         self.engine = AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i.reshape(E, P, 3),
                                   self._pred_j.reshape(E, P, 3), self.conf_trf(self._conf_i).reshape(E, P),
                                   self.conf_trf(self._conf_j).reshape(E, P), self.imshapes, mono=None,
@@ -118,8 +119,9 @@ class PointCloudOptimizer(_Base):
                                   norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device,
                                   shared_focal=self.shared_focal, temporal_smoothing_weight=float(self.temporal_smoothing_weight),
                                   translation_weight=float(self.translation_weight), flow=self._flow, **self._flags)
-        self.engine.set_params(**self._init)
-        self._pred_i = self._pred_j = self._conf_i = self._conf_j = None
+        self.engine.set_params(**(state or self._init))
+        self._pred_i, self._pred_j = self.engine.pred_i, self.engine.pred_j
+        self._conf_i, self._conf_j = self._raw_conf_i, self._raw_conf_j
         return self
 
     @property

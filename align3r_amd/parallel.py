@@ -3,79 +3,86 @@
 New design (the reference runs inference single-process, dust3r/inference.py:55-72):
 frame pairs are independent, so the edge list from make_pairs (identical on every rank, bit-exact) is
 cut into contiguous shards, one per rank (one process per GPU, torch.distributed: backend "nccl" is
-RCCL over xGMI on ROCm, "gloo" on CPU for the tests).  The only exchange on the data path is ONE
-all-gather of {pts3d, conf, pts3d_in_other_view, conf} (32 B per pixel per pair), after which every
-rank holds the full inference output in the original edge order, exactly what ``inference()`` returns.
+RCCL over xGMI on ROCm, "gloo" on CPU for the tests).  The only exchange on the data path is the
+all-gather of {pts3d, conf, pts3d_in_other_view, conf} (32 B per pixel per pair).
+
+Layout: the four gathered buffers ARE the aligner's stacked observation buffers
+(`_stacked_pred_i/j [E,P,3]`, conf `[E,P]`, dust3r/cloud_opt/optimizer.py:60-67) in the original edge order.
+Every rank owns rows [rank*n_max, rank*n_max + n_max) of buffers with world*n_max >= E rows (shard_rows),
+writes its forward results straight into its rows and the collective is an IN-PLACE all-gather (the send
+buffer is the rank's own slice of the receive buffer): no packing, no re-ordering, no copy afterwards --
+`pred1['pts3d']` etc. returned to the caller are views of the first E rows, and PointCloudOptimizer.to()
+hands them to the HIP aligner without another copy when they already live on its device.
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
-from .dust3r.image_pairs import shard_pairs
 from .dust3r.utils.device import collate_with_cat
 
 _KEYS = (("pred1", "pts3d", 3), ("pred1", "conf", 1), ("pred2", "pts3d_in_other_view", 3), ("pred2", "conf", 1))
 
 
-def gather_pair_outputs(local, n_pairs, H, W, group=None):
-    """local: dict(pred1={pts3d [n_loc,H,W,3], conf [n_loc,H,W]}, pred2={pts3d_in_other_view, conf}) for this
-    rank's contiguous shard.  Returns the same structure for all n_pairs pairs, identical on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
-        return local
-    lo, hi = shard_pairs(n_pairs, rank, world)
+def shard_rows(n_pairs: int, rank: int, world_size: int):
+    """(lo, hi, n_max): rank's contiguous shard [lo, hi) when every rank owns a block of n_max = ceil(n/world) rows.
+    The longest shard -- which sets the wall time -- has the same length as with an 'even' split (shard_pairs); the
+    blocks being equal is what lets the collective gather straight into edge order.  Trailing ranks may get fewer (or no) pairs."""
+    n_max = (n_pairs + world_size - 1) // world_size
+    lo = min(rank * n_max, n_pairs)
+    return lo, min(lo + n_max, n_pairs), n_max
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def alloc_gather_buffers(n_pairs, H, W, device, group=None):
+    """The four stacked buffers with world*n_max rows each (rows >= n_pairs are slack that is never read)."""
+    world, _ = _world(group)
     n_max = (n_pairs + world - 1) // world
-    P = H * W
-    dev = local["pred1"]["conf"].device
-    # one packed buffer per rank: [n_max, P, 8] = pts1(3) conf1(1) pts2(3) conf2(1)  -> a single collective
-    send = torch.zeros(n_max, P, 8, device=dev, dtype=torch.float32)
-    n_loc = hi - lo
-    if n_loc:
-        send[:n_loc, :, 0:3] = local["pred1"]["pts3d"].reshape(n_loc, P, 3)
-        send[:n_loc, :, 3] = local["pred1"]["conf"].reshape(n_loc, P)
-        send[:n_loc, :, 4:7] = local["pred2"]["pts3d_in_other_view"].reshape(n_loc, P, 3)
-        send[:n_loc, :, 7] = local["pred2"]["conf"].reshape(n_loc, P)
-    recv = torch.empty(world, n_max, P, 8, device=dev, dtype=torch.float32)
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-    else:
-        chunks = [recv[r] for r in range(world)]
-        dist.all_gather(chunks, send, group=group)
-    parts = []
-    for r in range(world):
-        a, b = shard_pairs(n_pairs, r, world)
-        parts.append(recv[r, :b - a])
-    full = torch.cat(parts, 0)          # original edge order
-    return dict(pred1=dict(pts3d=full[:, :, 0:3].reshape(n_pairs, H, W, 3).contiguous(), conf=full[:, :, 3].reshape(n_pairs, H, W).contiguous()),
-                pred2=dict(pts3d_in_other_view=full[:, :, 4:7].reshape(n_pairs, H, W, 3).contiguous(),
-                           conf=full[:, :, 7].reshape(n_pairs, H, W).contiguous()))
+    rows = world * n_max
+    z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)
+    return dict(pts1=z(rows, H, W, 3), conf1=z(rows, H, W), pts2=z(rows, H, W, 3), conf2=z(rows, H, W))
 
 
-def sharded_inference(pairs, forward_fn, device, batch_size=8, group=None):
+def gather_in_place(bufs, n_pairs, group=None, force=False):
+    """In-place all-gather of the rank blocks of the four buffers (each rank has already filled its own block).
+    force: issue the collective even in a 1-rank group (exercises the RCCL call on a one-GPU box)."""
+    world, rank = _world(group)
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
+        return bufs
+    n_max = (n_pairs + world - 1) // world
+    for t in bufs.values():
+        flat = t.view(world, -1)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(t.view(-1), flat[rank], group=group)      # RCCL, in place: send = own slice of recv
+        else:
+            dist.all_gather([flat[r] for r in range(world)], flat[rank].clone(), group=group)
+    return bufs
+
+
+def sharded_inference(pairs, forward_fn, device, batch_size=8, group=None, force_collective=False):
     """inference() over this rank's shard + all-gather.  ``forward_fn(view1, view2) -> (res1, res2)`` is the model
-    call (AsymmetricCroCo3DStereo.__call__).  Returns {view1, view2, pred1, pred2, loss} for ALL pairs."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    call (AsymmetricCroCo3DStereo.__call__).  Returns {view1, view2, pred1, pred2, loss} for ALL pairs, the pred tensors
+    living on `device` (views of the gathered buffers)."""
+    world, rank = _world(group)
     n = len(pairs)
-    lo, hi = shard_pairs(n, rank, world)
+    lo, hi, _ = shard_rows(n, rank, world)
     H, W = pairs[0][0]["img"].shape[-2:]
-    res1s, res2s = [], []
+    bufs = alloc_gather_buffers(n, H, W, device, group)
     for i in range(lo, hi, batch_size):
-        view1, view2 = collate_with_cat(pairs[i:min(i + batch_size, hi)])
+        j = min(i + batch_size, hi)
+        view1, view2 = collate_with_cat(pairs[i:j])
         r1, r2 = forward_fn(view1, view2)
-        res1s.append(r1)
-        res2s.append(r2)
-    if res1s:
-        local = dict(pred1=dict(pts3d=torch.cat([r["pts3d"] for r in res1s]), conf=torch.cat([r["conf"] for r in res1s])),
-                     pred2=dict(pts3d_in_other_view=torch.cat([r["pts3d_in_other_view"] for r in res2s]),
-                                conf=torch.cat([r["conf"] for r in res2s])))
-    else:
-        z = lambda *s: torch.zeros(*s, device=device)
-        local = dict(pred1=dict(pts3d=z(0, H, W, 3), conf=z(0, H, W)), pred2=dict(pts3d_in_other_view=z(0, H, W, 3), conf=z(0, H, W)))
-    full = gather_pair_outputs(local, n, H, W, group)
+        bufs["pts1"][i:j] = r1["pts3d"]
+        bufs["conf1"][i:j] = r1["conf"]
+        bufs["pts2"][i:j] = r2["pts3d_in_other_view"]
+        bufs["conf2"][i:j] = r2["conf"]
+    gather_in_place(bufs, n, group, force=force_collective)
     view1, view2 = collate_with_cat(pairs)
-    full["pred1"]["pred_mask"] = [0] * n
-    full["pred2"]["pred_mask"] = [0] * n
-    return dict(view1=view1, view2=view2, pred1=full["pred1"], pred2=full["pred2"], loss=None)
+    return dict(view1=view1, view2=view2,
+                pred1=dict(pts3d=bufs["pts1"][:n], conf=bufs["conf1"][:n], pred_mask=[0] * n),
+                pred2=dict(pts3d_in_other_view=bufs["pts2"][:n], conf=bufs["conf2"][:n], pred_mask=[0] * n), loss=None)

@@ -35,18 +35,20 @@ FLOP_PER_PAIR = {(384, 512): 1969.1e9, (288, 512): 1436.1e9, (224, 224): 461.2e9
 
 
 def pmc_traffic(kernel):
-    """HBM/fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs, gfx950 correction applied).  PMC counters cannot be read from inside this
-    process, so this is the number of the profiled run of the same command, or None when no such file is committed."""
+    """(bytes per launch, source tag): HBM/fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r*_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, gfx950 correction applied).  PMC
+    counters cannot be read from inside this process, so this is the number of the profiled run of the same command; the tag names
+    the profile it came from (a profile older than the kernels it describes is stale -- tools/profile_round.sh regenerates it).
+    (None, None) when no such file is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
-            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"]
+            return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"], os.path.basename(files[-1])
     except (KeyError, ValueError, OSError):
-        return None
+        return None, None
 
 
 def parse():
@@ -67,8 +69,31 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare shell (no torchrun, WORLD_SIZE unset): start the N ranks as fresh child processes,
+    one per GPU, through torch.distributed.run -- BEFORE anything in this process touches the GPU (this parent imports neither
+    torch nor the HIP library, it only waits and passes rank 0's JSON line through) -- and exit with the children's code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    # A3R_BENCH_SELF_LAUNCH=1 forces the launcher for --gpus 1 too (rehearsal of the path on a one-GPU box)
+    if (a.gpus > 1 or os.environ.get("A3R_BENCH_SELF_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     from align3r_amd import _lib
@@ -76,6 +101,7 @@ def main():
     from align3r_amd.engine import PairEngine
     from align3r_amd.aligner import AlignEngine
     from align3r_amd.dust3r.image_pairs import make_pairs
+    from align3r_amd.parallel import gather_in_place
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,11 +110,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # A3R_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, barrier, all-reduce) with a single rank too
-    use_dist = world > 1 or os.environ.get("A3R_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or os.environ.get("A3R_BENCH_FORCE_DIST") == "1" or os.environ.get("A3R_BENCH_SELF_LAUNCH") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                  # proof that `world` ranks took part over RCCL
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world
+    else:
+        rccl_ranks = None
 
     H, W, B = a.height, a.width, a.batch
     P = H * W
@@ -110,15 +142,17 @@ def main():
 
     n_batches = min(a.steps + a.warmup, (E + B - 1) // B)
     inputs = [batch_inputs(s) for s in range(n_batches)]          # resident in HBM before timing
-    flat = torch.empty(B * P * 8, device=dev)                      # one step's outputs, contiguous for the collective
-    out = dict(pts3d_1=flat[:B * P * 3].view(B, H, W, 3), pts3d_2=flat[B * P * 3:B * P * 6].view(B, H, W, 3),
-               conf_1=flat[B * P * 6:B * P * 7].view(B, H, W), conf_2=flat[B * P * 7:].view(B, H, W))
-    gathered = torch.empty(world * B * P * 8, device=dev) if use_dist else None
+    # The step's outputs land directly in this rank's rows of the stacked aligner buffers ([world*B, H, W, 3] / [world*B, H, W]:
+    # rank r owns rows [r*B, (r+1)*B)); the collective is the in-place all-gather of align3r_amd.parallel -- no packing, no copy.
+    bufs = dict(pts1=torch.empty(world * B, H, W, 3, device=dev), conf1=torch.empty(world * B, H, W, device=dev),
+                pts2=torch.empty(world * B, H, W, 3, device=dev), conf2=torch.empty(world * B, H, W, device=dev))
+    mine = slice(rank * B, (rank + 1) * B)
+    out = dict(pts3d_1=bufs["pts1"][mine], conf_1=bufs["conf1"][mine], pts3d_2=bufs["pts2"][mine], conf_2=bufs["conf2"][mine])
 
     def step(s):
         eng.forward(*inputs[s % n_batches], out=out)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, flat)
+            gather_in_place(bufs, world * B)
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,7 +179,7 @@ def main():
     byname = {p["name"]: p for p in prof}
     lin_bf3 = byname.get("gemm_bf3_kernel (linear, split-bf16 MFMA)")
     use_bf3 = bool(lin_bf3 and lin_bf3["launches"])
-    lin = lin_bf3 if use_bf3 else prof[0]
+    lin = lin_bf3 if use_bf3 else byname["gemm_kernel<0> (linear)"]
     achieved = lin["work"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
     # roofline of the dominant kernel.  fp32 MFMA kernel: algorithmic fp32 FLOP against the fp32 MFMA peak.  bf3 kernel: it
     # executes SIX bf16 MFMA flops per algorithmic fp32 flop, so its ceiling for ALGORITHMIC flops is bf16 peak / 6.
@@ -155,6 +189,9 @@ def main():
                                rate=round(p["work"] / (p["ms"] * 1e-3) / 1e12, 3) if p["ms"] > 0 else None)
                for p in prof if p["launches"]}
     flop_pair = FLOP_PER_PAIR.get((H, W))
+    lin_traffic, lin_traffic_src = (pmc_traffic("gemm_bf3_kernel" if use_bf3 else "gemm_kernel<0>") if (B, H, W) == (42, 384, 512)
+                                    else (None, None))
+    lin_bytes = lin.get("bytes", 0.0) / max(lin["launches"], 1)
     res = {
         "metric": "frame-pairs/s ViT-L 512px + global-align iters/s, 1/2/4/8 MI355X", "value": round(pairs_per_s, 4),
         "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -167,6 +204,10 @@ def main():
                                f"{B} pairs/step/GPU, cloud_opt PointCloudOptimizer", "pairs_per_step_per_gpu": B,
                    "frames": a.frames, "edges": E, "parallelism": f"pair-shard x{world}" + (" + all-gather/step" if world > 1 else "")},
         "model_tflops_as_reference": round(pairs_per_s * flop_pair / 1e12 / world, 2) if flop_pair else None,
+        "model_tflops_note": ("per GPU; uses the REFERENCE's FLOP count per pair (SURVEY.md 8d: 1969.1 GFLOP at 512x384), not the executed "
+                              "count -- the plan runs each DPT fusion block's 1x1 out_conv before the bilinear 2x (a quarter of the rows), "
+                              "so it executes ~0.7 % fewer FLOP than the reference for the same result"),
+        "rccl_ranks": rccl_ranks,
         "roofline": {"bound": "mfma",
                      "kernel": ("gemm_bf3_kernel (nn.Linear on the bf16 matrix cores: exact 3-plane split of both fp32 operands, "
                                 "6 bf16 MFMA passes, fp32 accumulate)" if use_bf3 else "gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)"),
@@ -175,7 +216,9 @@ def main():
                                    f"{6 * achieved:.0f} TFLOP/s; the exact-fp32 MFMA peak is {PEAK_F32_MFMA_TFLOPS}" if use_bf3
                                    else "v_mfma_f32_32x32x2_f32 dense peak"),
                      "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": pmc_traffic("gemm_bf3_kernel" if use_bf3 else "gemm_kernel<0>") if (B, H, W) == (42, 384, 512) else None,
+                     "traffic": lin_traffic, "traffic_source": lin_traffic_src,
+                     "algorithmic_bytes_per_launch": round(lin_bytes) if lin_bytes else None,
+                     "traffic_over_algorithmic": round(lin_traffic / lin_bytes, 2) if (lin_traffic and lin_bytes) else None,
                      "algorithmic_flop_per_launch": round(lin["work"] / max(lin["launches"], 1)),
                      "launches": lin["launches"], "avg_launch_us": round(1e3 * lin["ms"] / max(lin["launches"], 1), 2)},
         "kernels": kernels,
@@ -227,13 +270,14 @@ def main():
         torch.cuda.synchronize()
         dta = time.perf_counter() - t0
         _lib.prof_enable(False)
-        pa = _lib.prof_report()[5]
+        pbn = {p["name"]: p for p in _lib.prof_report()}
+        pa = pbn["align_main_kernel"]
         gbs = pa["work"] / (pa["ms"] * 1e-3) / 1e9 if pa["ms"] > 0 else 0.0
         res["align_iters_per_s"] = round(a.align_iters / dta, 2)
         res["align_config"] = {"N": N, "E": E, "P": P, "use_mono": False, "iters": a.align_iters}
         res["roofline_align"] = {"bound": "hbm", "kernel": "align_main_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                 "traffic": pmc_traffic("align_main_kernel") if (a.frames, E, P) == (16, 84, 196608) else None,
+                                 "traffic": pmc_traffic("align_main_kernel")[0] if (a.frames, E, P) == (16, 84, 196608) else None,
                                  "bytes_per_iter": pa["work"] / max(pa["launches"], 1), "avg_launch_us": round(1e3 * pa["ms"] / max(pa["launches"], 1), 2)}
         del al
 

@@ -49,6 +49,9 @@ int a3r_device_count(void);
 int a3r_prof_enable(int on);
 int a3r_prof_kernel_count(void);
 int a3r_prof_get(int kernel, const char** name, long* launches, double* total_ms, double* total_work);
+/* Summed ALGORITHMIC bytes of the MFMA-bound kernel classes (every operand read once, every result written once; 0 for classes
+ * whose `work` already is a byte count): lets bench.py print algorithmic bytes per launch next to the PMC traffic. */
+int a3r_prof_get_bytes(int kernel, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * (1) 2-D rotary embedding, in place.  Replaces curope.rope_2d(tokens, positions, base, fwd)
@@ -306,6 +309,11 @@ typedef struct {
     size_t workspace_bytes;
     float* loss_history;         /* [loss_capacity]; entry t = loss of iteration t (before its update) */
     int loss_capacity;
+    /* allow_pw_adaptors=True (base_opt.py:117-118,177-182): pw_adaptors [E,2] = (xy, z) log-scale adaptation of each pairwise
+     * prediction become trainable: gradient + Adam like every other small parameter.  adam_pw_adaptors [2, E, 2] (zero-initialised)
+     * is required when train_adaptors != 0 and ignored otherwise. */
+    int train_adaptors;
+    float* adam_pw_adaptors;
 } a3r_align_desc;
 
 typedef struct a3r_align_s* a3r_align_t;
@@ -321,6 +329,9 @@ int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream);
 /* Gradients of the current state without updating (for the parity tests):
  * g_pw_poses [E,8], g_depth [N,P], g_small [N,16] (layout of adam_small), loss_dev [1]. */
 int a3r_align_grad(a3r_align_t a, float* g_pw_poses, float* g_depth, float* g_small, float* loss_dev, void* stream);
+/* the same with the gradient of pw_adaptors [E,2] as well (g_pw_adaptors may be NULL); epoch as a3r_align_grad_epoch */
+int a3r_align_grad_full(a3r_align_t a, int epoch, float* g_pw_poses, float* g_pw_adaptors, float* g_depth, float* g_small,
+                        float* loss_dev, void* stream);
 /* cloud_opt_flow variant (dust3r/cloud_opt_flow/optimizer.py:36-116,500-572): shared focal, temporal smoothing of
  * consecutive image poses (relative_pose_loss), ego-flow smooth-L1 term against precomputed optical flow (the RAFT
  * fields and the dynamic masks are INPUTS).  Call once after a3r_align_create (not with use_mono).  With shared_focal

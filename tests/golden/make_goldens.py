@@ -295,6 +295,28 @@ def gen_vitl(out):
     print("vitl:", meta)
 
 
+def gen_vitlhi(out):
+    """ViT-L at the resolutions of BASELINE configs 2 and 3: ONE pair (0,1) each at 384x512 (frames seed 2) and 288x512 (frames
+    seed 3) through the reference's inference(bs=1) on CPU -- the same seeded inputs tests/test_gpu_model.py feeds the HIP engine
+    and the numpy oracle.  Stored: stride-4 sub-sampled maps + full-tensor statistics (as vitl_cfg1)."""
+    model = ref_model(VITL, img_size=(512, 512))
+    g, meta = {}, {}
+    for tag, H, W, seed in (("c2", 384, 512, 2), ("c3", 288, 512, 3)):
+        views = make_views(2, H, W, seed=seed)
+        r = _run_inference(model, views, [(0, 1)])
+        m = {}
+        for name, t in (("pts3d_1", r["pred1"]["pts3d"]), ("conf_1", r["pred1"]["conf"]),
+                        ("pts3d_2", r["pred2"]["pts3d_in_other_view"]), ("conf_2", r["pred2"]["conf"])):
+            a = t.numpy()
+            g[f"{tag}_{name}"] = a[:, ::4, ::4].copy()
+            m[name] = stats(a)
+        meta[tag] = dict(H=H, W=W, seed=seed, pairs=[(0, 1)], stride=4, stats=m)
+        print("vitlhi", tag, m["pts3d_1"])
+    np.savez_compressed(os.path.join(out, "vitl_hires.npz"), **g)
+    with open(os.path.join(out, "vitl_hires.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def _align_scene(kind, N, H, W, seed):
     """Synthetic inference output for the aligner. kind 'random': preds ~ N(0,1) (SURVEY 8d);
     kind 'geom': a bumpy surface seen by N cameras on a small arc, preds = true points in

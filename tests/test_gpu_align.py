@@ -122,6 +122,41 @@ def test_against_oracle_on_other_graphs(name, N, H, W, mono, dist, Engine):
         assert rel_err(host(a.params[k]).reshape(o.params[k].shape), o.params[k]) < 1e-4, k
 
 
+def test_config2_full_size_vs_oracle(Engine):
+    """BASELINE config 2's alignment problem at FULL size -- N = 16, swin-3-noncyclic symmetrised (E = 84), P = 384 x 512 = 196608
+    (192 chunks of 1024 pixels per image, 0.6 GB per iteration: the problem bench.py times) -- against oracle/align_ref.c:
+    loss and every gradient of the first evaluation (1e-6 / 1e-5), then 8 Adam steps (losses 1e-5, parameter states 1e-4),
+    and the loss must go down."""
+    from conftest import record_margin
+    from oracle.align_ref import AlignOracle
+    from align3r_amd.dust3r.image_pairs import make_pairs
+    N, H, W = 16, 384, 512
+    pairs = make_pairs([dict(idx=i) for i in range(N)], "swin-3-noncyclic", symmetrize=True)
+    edges = [(a["idx"], b["idx"]) for a, b in pairs]
+    assert len(edges) == 84
+    edges, p1, p2, w1, w2, m, init = _scene(edges, N, H, W, 21, False)
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(H, W)] * N)
+    o = AlignOracle(*args)
+    a = Engine(*args)
+    for eng in (o, a):
+        eng.set_params(**init)
+    lo, go = o.loss_grad()
+    la, ga = a.loss_grad()
+    margins = dict(loss0=abs(lo - la) / lo)
+    for k in go:
+        margins[f"grad_{k}"] = rel_err(host(ga[k]).reshape(go[k].shape), go[k])
+    lo = np.asarray(o.run(8, 0.05, "cosine"))
+    la = a.run(8, 0.05, "cosine")
+    margins["losses"] = rel_err(la, lo)
+    for k in o.trainable():
+        margins[f"state_{k}"] = rel_err(host(a.params[k]).reshape(o.params[k].shape), o.params[k])
+    record_margin("align_config2_full_size_vs_oracle", **margins)
+    assert margins["loss0"] < 1e-6
+    assert all(v < 1e-5 for k, v in margins.items() if k.startswith("grad_")), margins
+    assert margins["losses"] < 1e-5 and la[-1] < la[0]
+    assert all(v < 1e-4 for k, v in margins.items() if k.startswith("state_")), margins
+
+
 def test_frozen_poses_and_bad_edges(Engine):
     edges = [(0, 1), (1, 0), (1, 2), (2, 1)]
     edges, p1, p2, w1, w2, m, init = _scene(edges, 3, 16, 16, 5, False)

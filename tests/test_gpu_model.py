@@ -1,7 +1,15 @@
 """GPU: the whole HIP pair forward (a3r_model_forward through the C ABI) against
   (1) goldens produced by the reference itself (TINY end-to-end full tensors; ViT-L BASELINE config 1), and
   (2) the numpy oracle on the same seeded inputs at other sizes / batchings.
-Tolerance: north_star's 1e-4 relative fp32 (max-abs difference / tensor max)."""
+Tolerances: north_star's 1e-4 relative fp32, read two ways and asserted both ways: (a) max-abs difference / tensor max < 1e-4
+(TOL), (b) per element -- |dP|_2 / |P|_2 per pixel of a point map, |dc| / c per confidence -- with the bounds PT_TOL / CONF_TOL
+below (max, 99.9th percentile, 99th percentile).  The ViT-L point maps have a heavy tail (absmax ~800 vs median ~27 at 224x224),
+so (b) is the stricter statement for typical points.  What fp32 arithmetic delivers per point: |P| = expm1(d) is ill-conditioned
+where the predicted distance d -> 0, so a handful of near-origin pixels of pts3d (view 1's own frame) differ by a few 1e-4
+between ANY two fp32 evaluation orders -- the numpy oracle against the reference's own CPU output shows (max 1.2e-4, p99.9 6e-5)
+on the same golden (tests/test_oracle_model.py) where the HIP engine shows (max 1.6e-4, p99.9 1.1e-4).  Asserted: 99 % of the
+points within 1e-4, 99.9 % within 2e-4, every point within 2e-3; confidences and pts3d_in_other_view within 1e-4 everywhere.
+The measured margins are printed by every test ([parity-margin] lines) and listed in DESIGN.md section 2."""
 import json
 import os
 
@@ -9,11 +17,13 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, make_view_arrays, rel_err
+from conftest import GOLDEN, make_view_arrays, pair_margins, record_margin, rel_err
 from align3r_amd.weights import TINY, VITL, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+PT_TOL = (2e-3, 2e-4, 1e-4)      # per-point relative error of a point map: (max over pixels, 99.9th, 99th percentile)
+CONF_TOL = (1e-4, 1e-4, 1e-4)    # per-element relative error of a confidence map
 
 
 def to_dev(*arrs):
@@ -68,9 +78,10 @@ def test_tiny_batching_invariance(tiny_engine, H, W):
     for n, (i, j) in enumerate(idx):
         one = tiny_engine.forward(*to_dev(v[i][0], v[j][0], v[i][1], v[j][1]))
         for k in full:
-            assert rel_err(host(one[k])[0], full[k][n]) < 1e-5, (n, k)
+            # bit for bit: the claim inference()'s internal re-batching (A3R_INFER_MIN_BATCH) rests on
+            assert np.array_equal(host(one[k])[0], full[k][n]), (n, k, rel_err(host(one[k])[0], full[k][n]))
             if n < 2:
-                assert rel_err(host(one[k])[0], two[k][n]) < 1e-5, (n, k)
+                assert np.array_equal(host(one[k])[0], two[k][n]), (n, k, rel_err(host(one[k])[0], two[k][n]))
 
 
 def test_vitl_config1_vs_reference_golden(vitl_engine):
@@ -82,9 +93,9 @@ def test_vitl_config1_vs_reference_golden(vitl_engine):
     pd1, pd2 = np.concatenate([v[1][1], v[0][1]]), np.concatenate([v[0][1], v[1][1]])
     r = vitl_engine.forward(*to_dev(img1, img2, pd1, pd2))
     s = meta["stride"]
+    pair_margins("vitl_cfg1_224_vs_reference", {k: host(t)[:, ::s, ::s] for k, t in r.items()}, {k: g[k] for k in r}, TOL, PT_TOL, CONF_TOL)
     for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
         out = host(r[k])
-        assert rel_err(out[:, ::s, ::s], g[k]) < TOL, k
         st = meta["stats"][k]
         assert abs(out.astype(np.float64).mean() - st["mean"]) < 1e-4 * st["absmax"], k
         assert abs(np.abs(out).max() - st["absmax"]) < 1e-3 * st["absmax"], k
@@ -96,8 +107,7 @@ def test_vitl_512x384_vs_oracle(vitl_engine):
     v = make_view_arrays(2, 384, 512, seed=2)
     r = vitl_engine.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
     ref = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
-    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
-        assert rel_err(host(r[k]), ref[k]) < TOL, k
+    pair_margins("vitl_512x384_vs_oracle", {k: host(t) for k, t in r.items()}, ref, TOL, PT_TOL, CONF_TOL)
 
 
 def test_vitl_288x512_vs_oracle(vitl_engine):
@@ -106,8 +116,49 @@ def test_vitl_288x512_vs_oracle(vitl_engine):
     v = make_view_arrays(2, 288, 512, seed=3)
     r = vitl_engine.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
     ref = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
-    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
-        assert rel_err(host(r[k]), ref[k]) < TOL, k
+    pair_margins("vitl_288x512_vs_oracle", {k: host(t) for k, t in r.items()}, ref, TOL, PT_TOL, CONF_TOL)
+
+
+@pytest.mark.parametrize("tag,H,W,seed", [("c2", 384, 512, 2), ("c3", 288, 512, 3)])
+def test_vitl_hires_vs_reference_golden(vitl_engine, tag, H, W, seed):
+    """One pair at the resolutions of BASELINE configs 2 / 3 against the REFERENCE's own inference() output
+    (tests/golden/vitl_hires.npz, stride-4 sub-sampled; generated by make_goldens.py --only vitlhi in the build container)."""
+    g = np.load(os.path.join(GOLDEN, "vitl_hires.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vitl_hires.json")))[tag]
+    v = make_view_arrays(2, H, W, seed=seed)
+    r = vitl_engine.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
+    s = meta["stride"]
+    out = {k: host(t)[:, ::s, ::s] for k, t in r.items()}
+    pair_margins(f"vitl_{W}x{H}_vs_reference", out, {k: g[f"{tag}_{k}"] for k in out}, TOL, PT_TOL, CONF_TOL)
+    for k, t in r.items():
+        st = meta["stats"][k]
+        assert abs(host(t).astype(np.float64).mean() - st["mean"]) < 1e-4 * st["absmax"], k
+
+
+def test_vitl_bench_plan_batch42(vitl_engine):
+    """The launch plan bench.py measures: B = 42 pairs of the 16-frame 512x384 clip in ONE forward (M = 64512 token rows, FULL-tile
+    GEMM variants, grouped launches, 25.7 GiB workspace).  Pairs 0, 20 and 41 of the batch must equal the B = 1 forward of the
+    same pair BIT FOR BIT (every output element is accumulated in the same order whatever tile the shape picks), and pair 0 is
+    checked against the numpy oracle."""
+    from oracle import model_np as O
+    from align3r_amd.dust3r.image_pairs import make_pairs
+    H, W, B = 384, 512, 42
+    v = make_view_arrays(16, H, W, seed=1)                       # bench.py's frames (rank 0)
+    pairs = make_pairs([dict(idx=i) for i in range(16)], "swin-3-noncyclic", symmetrize=True)
+    edges = [(p["idx"], q["idx"]) for p, q in pairs][:B]
+    cat = lambda side, k: np.concatenate([v[e[side]][k] for e in edges])
+    big = vitl_engine.forward(*to_dev(cat(0, 0), cat(1, 0), cat(0, 1), cat(1, 1)))
+    big = {k: t.clone() for k, t in big.items()}
+    for n in (0, 20, 41):
+        i, j = edges[n]
+        one = vitl_engine.forward(*to_dev(v[i][0], v[j][0], v[i][1], v[j][1]))
+        for k in big:
+            same = torch.equal(one[k][0], big[k][n])
+            record_margin(f"batch42_pair{n}_{k}", bitwise_equal=float(same), tensor_max=rel_err(host(big[k][n]), host(one[k][0])))
+            assert same, (n, k, rel_err(host(big[k][n]), host(one[k][0])))
+    i, j = edges[0]
+    ref = O.forward(v[i][0], v[j][0], v[i][1], v[j][1], synthetic_state_dict(VITL, 0), VITL)
+    pair_margins("vitl_batch42_pair0_vs_oracle", {k: host(t[:1]) for k, t in big.items()}, ref, TOL, PT_TOL, CONF_TOL)
 
 
 def test_shape_errors(tiny_engine):

@@ -68,3 +68,16 @@ def test_vitl_config1():
     s = meta["stride"]
     for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
         assert rel_err(r[k][:, ::s, ::s], g[k][:1]) < 1e-4, k
+
+
+def test_vitl_288x512_vs_reference_hires():
+    """The numpy oracle at BASELINE config 3's resolution against the reference's own output (vitl_hires.npz, one pair):
+    pins the oracle at a non-square, N = 576 token grid too.  Both the tensor-max and the per-point metric are checked."""
+    from conftest import pair_margins
+    g = np.load(os.path.join(GOLDEN, "vitl_hires.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "vitl_hires.json")))["c3"]
+    v = make_view_arrays(2, meta["H"], meta["W"], seed=meta["seed"])
+    r = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
+    s = meta["stride"]
+    out = {k: r[k][:, ::s, ::s] for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2")}
+    pair_margins("oracle_vitl_512x288_vs_reference", out, {k: g[f"c3_{k}"] for k in out}, 1e-4, (2e-3, 2e-4, 1e-4), (1e-4, 1e-4, 1e-4))
