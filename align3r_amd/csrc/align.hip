@@ -16,6 +16,9 @@
 //     adds in a fixed order: results are bitwise reproducible (no float atomics).
 //   * the pose / focal / scale parameters (a few KB) get their chain rule + Adam in two small kernels.
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <new>
 
@@ -37,7 +40,10 @@ struct AlignDev {
     float *adam_pw_poses, *adam_depth, *adam_small, *adam_pw_adaptors;
     // workspace
     float *edge_xf, *img_xf, *partE, *partN, *gE, *gN, *lossE, *gA;
-    const int *inc_ptr, *inc, *slot_of, *imw, *imarea;
+    float *sumE, *sumN;               // [2E][16] per incidence slot, [N][16] per image: chunk partials added in a fixed order
+    int* tick;                        // [N + 1] arrival counters of the in-kernel tail: per image, then all images (zero between launches)
+    int fused_tail;                   // 1: the main kernel finishes the iteration itself (last-block-done tickets); 0: finalize A/B launches
+    const int *inc_ptr, *inc, *slot_of, *imw, *imarea, *order;
     float* loss_history;
     // cloud_opt_flow extras (a3r_align_set_flow); all zero / null for the plain cloud_opt aligner
     int shared_focal;
@@ -199,19 +205,52 @@ __device__ __forceinline__ void unpack_edge(const EdgeData<false>& e, float (*x)
     for (int i = 0; i < PXT; i++) { x[i][0] = e.x[i][0]; x[i][1] = e.x[i][1]; x[i][2] = e.x[i][2]; w[i] = e.w[i]; }
 }
 
+// the tail of an iteration (defined below the flow kernels)
+struct TailOut { float *g_pw, *g_small, *loss_out, *g_adapt; };
+__device__ void edge_chain(const AlignDev& d, int e, const double* s, bool loss_only);
+__device__ void image_chain(const AlignDev& d, int n, double* s);
+__device__ __forceinline__ void wave_sum_rows(const float* base, int nchunks, int lane, float* tot);
+template <int MODE>
+__device__ void finalize_b_body(const AlignDev& d, const AdamArgs& ad, const TailOut& o, float* sh, double (*shd)[4]);
+
+// Arrival of this workgroup on a ticket counter after its global stores (MI355X guide, Guideline 16 counter form): every storing
+// wave drains its stores, the workgroup meets, ONE lane releases at agent scope and draws a ticket; the workgroup that draws the
+// last ticket acquires at agent scope before any of its threads reads what the others stored.  Returns (to every thread) whether
+// this workgroup is that last one.  `flag` is one int of LDS.
+__device__ __forceinline__ bool arrive_last(int* counter, int expected, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // never let the ticket overtake the write-back (compiler hazard)
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == expected - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// >= 4 waves per SIMD: the streaming loop needs <= 128 VGPRs; the (cold) tail may not raise the allocation
 #ifndef A3R_ALIGN_MIN_WAVES
-#define A3R_ALIGN_MIN_WAVES 1
+#define A3R_ALIGN_MIN_WAVES 4
 #endif
 template <bool MONO, bool L2, int MODE, bool VEC>
-__global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
-    AlignDev d, AdamArgs ad, float* g_depth,
+__global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main_kernel(
+    AlignDev d, AdamArgs ad, float* g_depth, TailOut tout,
     // read-only, wave-uniform tables as noalias kernel arguments: the compiler can then use SCALAR loads
     // (s_load), which do not sit on the vector-memory counter -- with vector loads every lookup of the next
     // edge id drained the prefetched edge data (s_waitcnt vmcnt(0)) and serialised the loop
     const int* __restrict__ inc_ptr, const int* __restrict__ inc, const float* __restrict__ edge_xf,
-    const float* __restrict__ img_xf, const int* __restrict__ imw, const int* __restrict__ imarea) {
+    const float* __restrict__ img_xf, const int* __restrict__ imw, const int* __restrict__ imarea, const int* __restrict__ order) {
     __shared__ float red[2][EB][16][16];
-    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // images are dispatched longest first (order[] sorts them by their number of incident edge sides): the last round of
+    // workgroups is then made of the short ones
+    const int n = order[blockIdx.y], chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = d.P;
     const float* ix = img_xf + n * 16;
     float R[9], T[3];
@@ -373,7 +412,7 @@ __global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
         }
         buf ^= 1;
     }
-    if (MODE == 0) return;
+    if (MODE != 0) {
 
     // per-image sums and the per-pixel parameter (forward quantities are recomputed: cheaper than keeping them live)
     float accN[16], gout[PXT];
@@ -451,6 +490,49 @@ __global__ __launch_bounds__(TPB, A3R_ALIGN_MIN_WAVES) void align_main_kernel(
         for (int r = 0; r < 16; r++) s += red[0][0][r][tid];
         d.partN[((size_t)n * d.nchunks + chunk) * 16 + tid] = s;
     }
+    }   // MODE != 0
+    if (!d.fused_tail) return;
+
+    // ---- tail of the iteration inside this launch (no finalize launches): last-block-done tickets, two levels.
+    // Level 1, per image: the workgroup that completes image n adds the chunk partials of the image's incidence slots and of the
+    // image itself in a fixed order (one wave per row set: the order does not depend on who runs it -> bitwise reproducible).
+    __syncthreads();                                   // red[] is free again
+    int* flag = reinterpret_cast<int*>(&red[0][0][0][0]);
+    if (!arrive_last(d.tick + n, gridDim.x, flag)) return;
+    {
+        float tot[16];
+        for (int k = kbeg + wave; k < kend; k += TPB / 64) {
+            wave_sum_rows(d.partE + (size_t)k * d.nchunks * 16, d.nchunks, lane, tot);
+            if (lane < 16) d.sumE[k * 16 + lane] = tot[lane];
+        }
+        if (MODE != 0 && wave == 0) {
+            wave_sum_rows(d.partN + (size_t)n * d.nchunks * 16, d.nchunks, lane, tot);
+            if (lane < 16) d.sumN[n * 16 + lane] = tot[lane];
+        }
+    }
+    // Level 2: the workgroup that completes the last image runs the chain rules of all edges and images, then the single-block
+    // finalisation (scale coupling, loss, Adam on the small parameters, next iteration's transforms).
+    if (!arrive_last(d.tick + d.N, d.N, flag)) return;
+    for (int e = tid; e < d.E; e += TPB) {
+        const float* s0 = d.sumE + d.slot_of[e * 2 + 0] * 16;
+        const float* s1 = d.sumE + d.slot_of[e * 2 + 1] * 16;
+        double s[13];
+#pragma unroll
+        for (int j = 0; j < 13; j++) s[j] = (double)s0[j] + (double)s1[j];
+        edge_chain(d, e, s, MODE == 0);
+    }
+    for (int m = tid; m < d.N; m += TPB) {
+        double s[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) s[j] = (double)d.sumN[m * 16 + j];
+        image_chain(d, m, s);
+    }
+    for (int i = tid; i <= d.N; i += TPB)              // counters back to zero for the next launch (write-through stores)
+        __hip_atomic_store(d.tick + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                   // the chain-rule results are visible to the whole workgroup
+    float* sh = &red[0][0][0][0];
+    double (*shd)[4] = reinterpret_cast<double (*)[4]>(&red[1][0][0][0]);
+    finalize_b_body<MODE>(d, ad, tout, sh, shd);
 }
 
 // ------------------------------------------------------------------------------------------- depth prior (cloud_opt_flow)
@@ -696,134 +778,134 @@ __device__ double temporal_pair(const float* Ra, const float* Ta, const float* R
 }
 
 // ------------------------------------------------------------------------------------------- finalize A
-// grid E + N blocks of 64 threads: fixed-order sum of the chunk partials, chain rule for the small parameters.
+// Chain rule of one edge from its 13 sums (both sides added): loss, d/d pw_pose (quaternion, translation, log-scale before the
+// mean coupling) and d/d pw_adaptors.
+__device__ void edge_chain(const AlignDev& d, int e, const double* s, bool loss_only) {
+    d.lossE[e] = (float)s[12];
+    if (loss_only) return;
+    const float* p = d.pw_poses + e * 8;
+    const float* xf = d.edge_xf + e * 16;
+    float R[9], qn[4], nrm;
+    quat_to_R(p, R, qn, &nrm);
+    const double sc = xf[12];
+    const float a[3] = {xf[13], xf[14], xf[15]};
+    double G[9], dLds = 0.0;
+    for (int r = 0; r < 3; r++) {
+        for (int q = 0; q < 3; q++) {
+            G[r * 3 + q] = -sc * a[q] * s[r * 3 + q];
+            dLds -= (double)R[r * 3 + q] * a[q] * s[r * 3 + q];
+        }
+        dLds -= (double)signed_expm1f(p[4 + r]) * s[9 + r];
+    }
+    double gq[4];
+    quat_backward(qn, nrm, G, gq);
+    float* g = d.gE + e * 8;
+    for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
+    for (int k = 0; k < 3; k++) g[4 + k] = (float)(-sc * s[9 + k] * signed_expm1_grad(p[4 + k]));
+    g[7] = (float)(dLds * sc);   // S_e * s_e; the mean coupling is applied in finalize B
+    // pw_adaptors (base_opt.py:177-182): aligned = s R diag(a) X + s T with a = exp(adapt / pw_break),
+    // adapt = (p0, p0, p1) [- its mean when norm_pw_scale].  dL/da_c = - sum_r s R_rc (sum g_r X_c).
+    double ga[3], gmean = 0.0;
+    for (int c = 0; c < 3; c++) {
+        double t = 0.0;
+        for (int r = 0; r < 3; r++) t -= sc * (double)R[r * 3 + c] * s[r * 3 + c];
+        ga[c] = t * a[c] / d.pw_break;                   // w.r.t. the (centred) exponent
+        gmean += ga[c];
+    }
+    if (d.norm_pw_scale) { gmean /= 3.0; for (int c = 0; c < 3; c++) ga[c] -= gmean; }
+    d.gA[e * 2 + 0] = (float)(ga[0] + ga[1]);
+    d.gA[e * 2 + 1] = (float)ga[2];
+}
+
+// Chain rule of one image from its 16 sums (+ the ego-flow target-camera terms and the temporal smoothing term).
+// (in loss-only launches the partial sums are stale: only lossN is consumed)
+__device__ void image_chain(const AlignDev& d, int n, double* s) {
+    const float* p = d.im_poses + n * 7;
+    float R[9], qn[4], nrm;
+    quat_to_R(p, R, qn, &nrm);
+    if (d.flow_on) {
+        // image n as the TARGET camera of the ego-flow of the opposite side of each incident edge
+        const float fn = d.img_xf[n * 16 + 12];
+        for (int k = d.inc_ptr[n]; k < d.inc_ptr[n + 1]; k++) {
+            const int code = d.inc[k], opp = d.slot_of[(code >> 1) * 2 + (1 - (code & 1))];
+            const double c = d.flow_state[1 - (code & 1)];
+            const float* F = d.sumF + opp * NFP;
+            for (int j = 0; j < 9; j++) s[j] += c * F[8 + j];                       // dL/dR_t = v (x) gY
+            for (int i = 0; i < 3; i++)
+                s[9 + i] -= c * ((double)R[i * 3] * F[5] + (double)R[i * 3 + 1] * F[6] + (double)R[i * 3 + 2] * F[7]);
+            s[12] += c * F[2] * fn / d.focal_break;
+            s[13] += 10.0 * c * F[3];
+            s[14] += 10.0 * c * F[4];
+        }
+    }
+    if (d.tsw > 0.f) {
+        float Tn[3], Ro[9], To[3];
+        for (int k = 0; k < 3; k++) Tn[k] = signed_expm1f(p[4 + k]);
+        double GR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, GT[3] = {0, 0, 0};
+        if (n + 1 < d.N) {
+            const float* po = d.im_poses + (n + 1) * 7;
+            quat_to_R(po, Ro, nullptr, nullptr);
+            for (int k = 0; k < 3; k++) To[k] = signed_expm1f(po[4 + k]);
+            d.lossN[n] = (float)(d.tsw * temporal_pair(R, Tn, Ro, To, d.trans_w, 0, GR, GT));
+        } else {
+            d.lossN[n] = 0.f;
+        }
+        if (n > 0) {
+            const float* po = d.im_poses + (n - 1) * 7;
+            quat_to_R(po, Ro, nullptr, nullptr);
+            for (int k = 0; k < 3; k++) To[k] = signed_expm1f(po[4 + k]);
+            temporal_pair(Ro, To, R, Tn, d.trans_w, 1, GR, GT);
+        }
+        for (int j = 0; j < 9; j++) s[j] += d.tsw * GR[j];
+        for (int j = 0; j < 3; j++) s[9 + j] += d.tsw * GT[j];
+    }
+    double gq[4];
+    quat_backward(qn, nrm, s, gq);
+    float* g = d.gN + n * 16;
+    for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
+    for (int k = 0; k < 3; k++) g[4 + k] = (float)(s[9 + k] * signed_expm1_grad(p[4 + k]));
+    g[7] = (float)s[12]; g[8] = (float)s[13]; g[9] = (float)s[14]; g[10] = (float)s[15];
+    for (int k = 11; k < 16; k++) g[k] = 0.f;
+}
+
+// One wave: fixed-order sum of the nchunks 16-float partial rows at `base`; every lane returns the 16 totals in tot[].
+// lane = 4 c' + q reads floats [4q, 4q+4) of chunks c', c' + 16, ... (16-byte loads), then the 16 lanes that share q are
+// added by xor-shuffles (4, 8, 16, 32): the order never depends on which wave or workgroup runs it.
+__device__ __forceinline__ void wave_sum_rows(const float* base, int nchunks, int lane, float* tot /*[16]*/) {
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    const int q = lane & 3;
+    const f32x4* pe = reinterpret_cast<const f32x4*>(base);
+    for (int c = lane >> 2; c < nchunks; c += 16) part += pe[c * 4 + q];
+    float pv[4] = {part.x, part.y, part.z, part.w};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float v = pv[t];
+        v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        pv[t] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) tot[j] = __shfl(pv[j & 3], j >> 2);
+}
+
+// Separate-launch form (A3R_ALIGN_TAIL=launch): grid E + N blocks of 64 threads.
 __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int loss_only) {
     const int b = blockIdx.x, lane = threadIdx.x;
+    float t0[16], t1[16];
     if (b < d.E) {
-        const int e = b;
-        // 4 lanes per chunk row: lane = 4*c' + q reads floats [4q, 4q+4) of chunk c' (16-byte loads), fixed order
-        f32x4 part = {0.f, 0.f, 0.f, 0.f};
-        const int q = lane & 3;
-        for (int side = 0; side < 2; side++) {
-            const int k = d.slot_of[e * 2 + side];
-            const f32x4* pe = reinterpret_cast<const f32x4*>(d.partE + (size_t)k * d.nchunks * 16);
-            for (int c = lane >> 2; c < d.nchunks; c += 16) {
-                const f32x4 v = pe[c * 4 + q];
-                part += v;
-            }
-        }
-        // sum over the 16 lanes that share q (lanes q, q+4, ...): xor 4, 8, 16, 32
-        float pv[4] = {part.x, part.y, part.z, part.w};
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            float v = pv[t];
-            v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            pv[t] = v;
-        }
-        // lane q now holds totals of floats 4q..4q+3; gather the 13 used values to every lane
-        double s[13];
-#pragma unroll
-        for (int j = 0; j < 13; j++) s[j] = (double)__shfl(pv[j & 3], j >> 2);
+        wave_sum_rows(d.partE + (size_t)d.slot_of[b * 2 + 0] * d.nchunks * 16, d.nchunks, lane, t0);
+        wave_sum_rows(d.partE + (size_t)d.slot_of[b * 2 + 1] * d.nchunks * 16, d.nchunks, lane, t1);
         if (lane == 0) {
-            d.lossE[e] = (float)s[12];
-            if (!loss_only) {
-                const float* p = d.pw_poses + e * 8;
-                const float* xf = d.edge_xf + e * 16;
-                float R[9], qn[4], nrm;
-                quat_to_R(p, R, qn, &nrm);
-                const double sc = xf[12];
-                const float a[3] = {xf[13], xf[14], xf[15]};
-                double G[9], dLds = 0.0;
-                for (int r = 0; r < 3; r++) {
-                    for (int q = 0; q < 3; q++) {
-                        G[r * 3 + q] = -sc * a[q] * s[r * 3 + q];
-                        dLds -= (double)R[r * 3 + q] * a[q] * s[r * 3 + q];
-                    }
-                    dLds -= (double)signed_expm1f(p[4 + r]) * s[9 + r];
-                }
-                double gq[4];
-                quat_backward(qn, nrm, G, gq);
-                float* g = d.gE + e * 8;
-                for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
-                for (int k = 0; k < 3; k++) g[4 + k] = (float)(-sc * s[9 + k] * signed_expm1_grad(p[4 + k]));
-                g[7] = (float)(dLds * sc);   // S_e * s_e; the mean coupling is applied in finalize B
-                // pw_adaptors (base_opt.py:177-182): aligned = s R diag(a) X + s T with a = exp(adapt / pw_break),
-                // adapt = (p0, p0, p1) [- its mean when norm_pw_scale].  dL/da_c = - sum_r s R_rc (sum g_r X_c).
-                double ga[3], gmean = 0.0;
-                for (int c = 0; c < 3; c++) {
-                    double t = 0.0;
-                    for (int r = 0; r < 3; r++) t -= sc * (double)R[r * 3 + c] * s[r * 3 + c];
-                    ga[c] = t * a[c] / d.pw_break;                   // w.r.t. the (centred) exponent
-                    gmean += ga[c];
-                }
-                if (d.norm_pw_scale) { gmean /= 3.0; for (int c = 0; c < 3; c++) ga[c] -= gmean; }
-                d.gA[e * 2 + 0] = (float)(ga[0] + ga[1]);
-                d.gA[e * 2 + 1] = (float)ga[2];
-            }
+            double s[13];
+            for (int j = 0; j < 13; j++) s[j] = (double)t0[j] + (double)t1[j];
+            edge_chain(d, b, s, loss_only != 0);
         }
     } else {
-        const int n = b - d.E;   // (in loss-only launches the partial sums are stale: only lossN is consumed)
-        f32x4 part = {0.f, 0.f, 0.f, 0.f};
-        const int q = lane & 3;
-        const f32x4* pn = reinterpret_cast<const f32x4*>(d.partN + (size_t)n * d.nchunks * 16);
-        for (int c = lane >> 2; c < d.nchunks; c += 16) part += pn[c * 4 + q];
-        float pv[4] = {part.x, part.y, part.z, part.w};
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            float v = pv[t];
-            v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            pv[t] = v;
-        }
-        double s[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) s[j] = (double)__shfl(pv[j & 3], j >> 2);
+        const int n = b - d.E;
+        wave_sum_rows(d.partN + (size_t)n * d.nchunks * 16, d.nchunks, lane, t0);
         if (lane == 0) {
-            const float* p = d.im_poses + n * 7;
-            float R[9], qn[4], nrm;
-            quat_to_R(p, R, qn, &nrm);
-            if (d.flow_on) {
-                // image n as the TARGET camera of the ego-flow of the opposite side of each incident edge
-                const float fn = d.img_xf[n * 16 + 12];
-                for (int k = d.inc_ptr[n]; k < d.inc_ptr[n + 1]; k++) {
-                    const int code = d.inc[k], opp = d.slot_of[(code >> 1) * 2 + (1 - (code & 1))];
-                    const double c = d.flow_state[1 - (code & 1)];
-                    const float* F = d.sumF + opp * NFP;
-                    for (int j = 0; j < 9; j++) s[j] += c * F[8 + j];                       // dL/dR_t = v (x) gY
-                    for (int i = 0; i < 3; i++)
-                        s[9 + i] -= c * ((double)R[i * 3] * F[5] + (double)R[i * 3 + 1] * F[6] + (double)R[i * 3 + 2] * F[7]);
-                    s[12] += c * F[2] * fn / d.focal_break;
-                    s[13] += 10.0 * c * F[3];
-                    s[14] += 10.0 * c * F[4];
-                }
-            }
-            if (d.tsw > 0.f) {
-                float Tn[3], Ro[9], To[3];
-                for (int k = 0; k < 3; k++) Tn[k] = signed_expm1f(p[4 + k]);
-                double GR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, GT[3] = {0, 0, 0};
-                if (n + 1 < d.N) {
-                    const float* po = d.im_poses + (n + 1) * 7;
-                    quat_to_R(po, Ro, nullptr, nullptr);
-                    for (int k = 0; k < 3; k++) To[k] = signed_expm1f(po[4 + k]);
-                    d.lossN[n] = (float)(d.tsw * temporal_pair(R, Tn, Ro, To, d.trans_w, 0, GR, GT));
-                } else {
-                    d.lossN[n] = 0.f;
-                }
-                if (n > 0) {
-                    const float* po = d.im_poses + (n - 1) * 7;
-                    quat_to_R(po, Ro, nullptr, nullptr);
-                    for (int k = 0; k < 3; k++) To[k] = signed_expm1f(po[4 + k]);
-                    temporal_pair(Ro, To, R, Tn, d.trans_w, 1, GR, GT);
-                }
-                for (int j = 0; j < 9; j++) s[j] += d.tsw * GR[j];
-                for (int j = 0; j < 3; j++) s[9 + j] += d.tsw * GT[j];
-            }
-            double gq[4];
-            quat_backward(qn, nrm, s, gq);
-            float* g = d.gN + n * 16;
-            for (int k = 0; k < 4; k++) g[k] = (float)gq[k];
-            for (int k = 0; k < 3; k++) g[4 + k] = (float)(s[9 + k] * signed_expm1_grad(p[4 + k]));
-            g[7] = (float)s[12]; g[8] = (float)s[13]; g[9] = (float)s[14]; g[10] = (float)s[15];
-            for (int k = 11; k < 16; k++) g[k] = 0.f;
+            double s[16];
+            for (int j = 0; j < 16; j++) s[j] = (double)t0[j];
+            image_chain(d, n, s);
         }
     }
 }
@@ -832,10 +914,8 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
 // one block: scale-normalisation coupling, loss, Adam on the small parameters, transforms for the next iteration.
 // MODE 0: loss only -> loss_out; 1: gradients -> g_pw / g_small / loss_out; 2: update.
 template <int MODE>
-__global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamArgs ad, float* g_pw, float* g_small,
-                                                               float* loss_out, float* g_adapt) {
-    __shared__ float sh[TPB];
-    __shared__ double shd[2][4];
+__device__ void finalize_b_body(const AlignDev& d, const AdamArgs& ad, const TailOut& o, float* sh /*[TPB]*/, double (*shd)[4] /*[2][4]*/) {
+    float* g_pw = o.g_pw; float* g_small = o.g_small; float* loss_out = o.loss_out; float* g_adapt = o.g_adapt;
     const int tid = threadIdx.x;
     double lsum = 0.0, ssum = 0.0;
     for (int e = tid; e < d.E; e += TPB) {
@@ -910,6 +990,13 @@ __global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamA
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(TPB) void align_finalize_b_kernel(AlignDev d, AdamArgs ad, TailOut o) {
+    __shared__ float sh[TPB];
+    __shared__ double shd[2][4];
+    finalize_b_body<MODE>(d, ad, o, sh, shd);
+}
+
 __global__ void align_export_xf_kernel(AlignDev d, float* edge_M, float* img_R) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.E * 12) edge_M[i] = d.edge_xf[(i / 12) * 16 + i % 12];
@@ -938,7 +1025,7 @@ static void refresh_if_dirty(a3r_align_s* a, hipStream_t st) {
     }
 }
 
-static size_t ws_layout(int E, int N, int P, size_t* off /*[13]*/) {
+static size_t ws_layout(int E, int N, int P, size_t* off /*[17]*/) {
     const int nch = (P + CHUNK - 1) / CHUNK;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -955,11 +1042,15 @@ static size_t ws_layout(int E, int N, int P, size_t* off /*[13]*/) {
     off[10] = take((size_t)N * 4);                  // imw
     off[11] = take((size_t)N * 4);                  // imarea
     off[12] = take((size_t)E * 2 * 4);              // gA
+    off[13] = take((size_t)2 * E * 16 * 4);         // sumE
+    off[14] = take((size_t)N * 16 * 4);             // sumN
+    off[15] = take((size_t)(N + 1) * 4);            // tick
+    off[16] = take((size_t)N * 4);                  // order
     return o;
 }
 
 extern "C" size_t a3r_align_workspace_bytes(int E, int N, int P) {
-    size_t off[13];
+    size_t off[17];
     return ws_layout(E, N, P, off);
 }
 
@@ -972,7 +1063,7 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     A3R_CHECK_ARG(!s->use_mono || (s->mono && s->shifts), "a3r_align_create: use_mono needs mono and shifts");
     A3R_CHECK_ARG(s->adam_pw_poses && s->adam_depth && s->adam_small, "a3r_align_create: missing Adam state");
     A3R_CHECK_ARG(s->loss_history && s->loss_capacity > 0, "a3r_align_create: missing loss_history");
-    size_t off[13];
+    size_t off[17];
     const size_t need = ws_layout(s->E, s->N, s->P, off);
     A3R_CHECK_ARG(!s->train_adaptors || s->adam_pw_adaptors, "a3r_align_create: train_adaptors needs adam_pw_adaptors");
     A3R_CHECK_ARG(s->workspace && s->workspace_bytes >= need, "a3r_align_create: workspace too small (%zu < %zu)",
@@ -1006,6 +1097,12 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     if (err == hipSuccess) err = up(off[9], slot.data(), 2 * s->E * 4);
     if (err == hipSuccess) err = up(off[10], s->imw_host, s->N * 4);
     if (err == hipSuccess) err = up(off[11], s->imarea_host, s->N * 4);
+    // dispatch order of the images: most incident edge sides first (stable: ties keep the image order)
+    std::vector<int> order(s->N);
+    for (int n = 0; n < s->N; n++) order[n] = n;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deg[x + 1] - deg[x] > deg[y + 1] - deg[y]; });
+    if (err == hipSuccess) err = up(off[16], order.data(), s->N * 4);
+    if (err == hipSuccess) err = hipMemsetAsync(ws + off[15], 0, (size_t)(s->N + 1) * 4, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);   // host vectors go out of scope
     if (err != hipSuccess) {
         delete a;
@@ -1027,6 +1124,12 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     d.partE = (float*)(ws + off[2]); d.partN = (float*)(ws + off[3]);
     d.gE = (float*)(ws + off[4]); d.gN = (float*)(ws + off[5]); d.lossE = (float*)(ws + off[6]);
     d.gA = (float*)(ws + off[12]);
+    d.sumE = (float*)(ws + off[13]); d.sumN = (float*)(ws + off[14]); d.tick = (int*)(ws + off[15]);
+    d.order = (const int*)(ws + off[16]);
+    {
+        const char* t = getenv("A3R_ALIGN_TAIL");       // developer A/B switch: "launch" = the separate finalize launches
+        d.fused_tail = (t && !strcmp(t, "launch")) ? 0 : 1;
+    }
     d.inc_ptr = (const int*)(ws + off[7]); d.inc = (const int*)(ws + off[8]); d.slot_of = (const int*)(ws + off[9]);
     d.imw = (const int*)(ws + off[10]); d.imarea = (const int*)(ws + off[11]);
     d.loss_history = s->loss_history;
@@ -1045,7 +1148,7 @@ extern "C" int a3r_align_destroy(a3r_align_t a) {
 }
 
 template <int MODE>
-static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, hipStream_t st) {
+static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, const TailOut& tout, hipStream_t st) {
     dim3 grid(a->d.nchunks, a->d.N), block(TPB);
     // algorithmic bytes of one iteration: 32 B per edge-pixel + 24 B per image-pixel (+4 mono)
     const double bytes = 32.0 * a->d.E * a->d.P + (MODE == 2 ? 24.0 : 4.0) * a->d.N * a->d.P + (a->use_mono ? 4.0 * a->d.N * a->d.P : 0.0);
@@ -1053,10 +1156,10 @@ static void launch_main(a3r_align_s* a, const AdamArgs& ad, float* g_depth, hipS
     const bool vec = a->d.P % 4 == 0;
 #define A3R_ALIGN_LAUNCH(MONOV, L2V)                                                                                      \
     do {                                                                                                                 \
-        if (vec) hipLaunchKernelGGL((align_main_kernel<MONOV, L2V, MODE, true>), grid, block, 0, st, a->d, ad, g_depth,   \
-                                    a->d.inc_ptr, a->d.inc, a->d.edge_xf, a->d.img_xf, a->d.imw, a->d.imarea);          \
-        else hipLaunchKernelGGL((align_main_kernel<MONOV, L2V, MODE, false>), grid, block, 0, st, a->d, ad, g_depth,     \
-                                a->d.inc_ptr, a->d.inc, a->d.edge_xf, a->d.img_xf, a->d.imw, a->d.imarea);              \
+        if (vec) hipLaunchKernelGGL((align_main_kernel<MONOV, L2V, MODE, true>), grid, block, 0, st, a->d, ad, g_depth, tout, \
+                                    a->d.inc_ptr, a->d.inc, a->d.edge_xf, a->d.img_xf, a->d.imw, a->d.imarea, a->d.order); \
+        else hipLaunchKernelGGL((align_main_kernel<MONOV, L2V, MODE, false>), grid, block, 0, st, a->d, ad, g_depth, tout, \
+                                a->d.inc_ptr, a->d.inc, a->d.edge_xf, a->d.img_xf, a->d.imw, a->d.imarea, a->d.order);  \
     } while (0)
     if (a->use_mono) {
         if (a->dist_l2) A3R_ALIGN_LAUNCH(true, true); else A3R_ALIGN_LAUNCH(true, false);
@@ -1167,11 +1270,12 @@ extern "C" int a3r_align_step_epoch(a3r_align_t a, float lr, int epoch, void* st
     ad.step = a->steps;
     refresh_if_dirty(a, st);
     launch_flow(a, epoch, st);
-    launch_main<2>(a, ad, nullptr, st);
-    {
+    const TailOut tout = {nullptr, nullptr, nullptr, nullptr};
+    launch_main<2>(a, ad, nullptr, tout, st);
+    if (!a->d.fused_tail) {
         ProfScope prof(PK_ALIGN_SMALL, 0.0, st);
         hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
-        hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((align_finalize_b_kernel<2>), dim3(1), dim3(TPB), 0, st, a->d, ad, tout);
     }
     A3R_LAUNCH_CHECK();
     a->steps++;
@@ -1188,9 +1292,12 @@ extern "C" int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream) {
     AdamArgs ad = {};
     refresh_if_dirty(a, st);
     launch_flow(a, 1 << 30, st);                                       // net() defaults to epoch=9999: flow term active
-    launch_main<0>(a, ad, nullptr, st);
-    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 1);
-    hipLaunchKernelGGL((align_finalize_b_kernel<0>), dim3(1), dim3(TPB), 0, st, a->d, ad, nullptr, nullptr, loss_dev, nullptr);
+    const TailOut tout = {nullptr, nullptr, loss_dev, nullptr};
+    launch_main<0>(a, ad, nullptr, tout, st);
+    if (!a->d.fused_tail) {
+        hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 1);
+        hipLaunchKernelGGL((align_finalize_b_kernel<0>), dim3(1), dim3(TPB), 0, st, a->d, ad, tout);
+    }
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -1202,9 +1309,12 @@ extern "C" int a3r_align_grad_full(a3r_align_t a, int epoch, float* g_pw_poses, 
     AdamArgs ad = {};
     refresh_if_dirty(a, st);
     launch_flow(a, epoch, st);
-    launch_main<1>(a, ad, g_depth, st);
-    hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
-    hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, g_pw_poses, g_small, loss_dev, g_pw_adaptors);
+    const TailOut tout = {g_pw_poses, g_small, loss_dev, g_pw_adaptors};
+    launch_main<1>(a, ad, g_depth, tout, st);
+    if (!a->d.fused_tail) {
+        hipLaunchKernelGGL(align_finalize_a_kernel, dim3(a->d.E + a->d.N), dim3(64), 0, st, a->d, 0);
+        hipLaunchKernelGGL((align_finalize_b_kernel<1>), dim3(1), dim3(TPB), 0, st, a->d, ad, tout);
+    }
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }

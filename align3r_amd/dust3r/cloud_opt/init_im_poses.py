@@ -88,7 +88,17 @@ def geotrf(trf, pts):
 
 def estimate_focals(pts3d):
     """Weiszfeld focals of B pointmaps [B,H,W,3] with the principal point at the centre (post_process.py:36-60), batched on the
-    device: one synchronisation for all of them.  Returns a list of B floats."""
+    device: one synchronisation for all of them.  Returns a list of B floats.  A list of maps of different shapes is processed
+    shape group by shape group."""
+    if isinstance(pts3d, (list, tuple)):
+        out = [None] * len(pts3d)
+        groups = {}
+        for k, p in enumerate(pts3d):
+            groups.setdefault(tuple(p.shape), []).append(k)
+        for ks in groups.values():
+            for k, f in zip(ks, estimate_focals(torch.stack([pts3d[k] for k in ks]))):
+                out[k] = f
+        return out
     B, H, W, _ = pts3d.shape
     if B > 256:                                   # bound the temporaries (a complete 64-frame graph has 4032 pointmaps)
         return [f for k in range(0, B, 256) for f in estimate_focals(pts3d[k:k + 256])]
@@ -183,18 +193,20 @@ def linear_pnp(pts3d, focal, msk, pp=None, irls_rounds=2):
 
 # ------------------------------------------------------------------------------------------------ the tree
 def compute_edge_scores(edges, conf_i, conf_j):
-    """mean(conf_i) * mean(conf_j) per edge (commons.py:20-25); conf_* [E,P]."""
-    si, sj = conf_i.mean(-1), conf_j.mean(-1)
+    """mean(conf_i) * mean(conf_j) per edge (commons.py:20-25); conf_*: per-edge maps (list, or a tensor with a leading E axis)."""
+    si = torch.stack([c.float().mean() for c in conf_i]).cpu()
+    sj = torch.stack([c.float().mean() for c in conf_j]).cpu()
     return {tuple(e): float(si[k] * sj[k]) for k, e in enumerate(edges)}
 
 
 def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_conf, min_conf_thr, device, init_priors=None,
                           has_im_poses=True, verbose=True):
-    """pred_* [E,H,W,3], conf_* [E,H,W] device tensors.  Returns (pts3d list, msp_edges, im_focals list, im_poses [N,4,4])."""
+    """pred_* [E,H,W,3], conf_* [E,H,W] device tensors, or per-edge lists when the images have different shapes.
+    Returns (pts3d list, msp_edges, im_focals list, im_poses [N,4,4])."""
     n_imgs = len(imshapes)
     E = len(edges)
     eidx = {tuple(e): k for k, e in enumerate(edges)}
-    scores = compute_edge_scores(edges, conf_i.reshape(E, -1), conf_j.reshape(E, -1))
+    scores = compute_edge_scores(edges, conf_i, conf_j)
     graph = sp.dok_array((n_imgs, n_imgs))
     for (i, j), v in scores.items():
         graph[i, j] = -v
@@ -276,14 +288,28 @@ def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_co
     return pts3d, msp_edges, im_focals, im_poses
 
 
+def edge_views(scene, dev):
+    """Per-edge [h,w,3] / [h,w] views of the engine's stacked (zero-filled to max_area) predictions and raw confidences: one
+    tensor per edge, shaped like the image it belongs to (side i: image i of the edge, side j: image j)."""
+    eng = scene.engine
+    E = len(scene.edges)
+    ci, cj = scene._raw_conf_i.to(dev).reshape(E, -1), scene._raw_conf_j.to(dev).reshape(E, -1)
+    if scene._uniform:
+        H, W = scene.imshape
+        return eng.pred_i.reshape(E, H, W, 3), eng.pred_j.reshape(E, H, W, 3), ci.reshape(E, H, W), cj.reshape(E, H, W)
+    sh = scene.imshapes
+    pi = [eng.pred_i[e, :sh[i][0] * sh[i][1]].view(*sh[i], 3) for e, (i, j) in enumerate(scene.edges)]
+    pj = [eng.pred_j[e, :sh[j][0] * sh[j][1]].view(*sh[j], 3) for e, (i, j) in enumerate(scene.edges)]
+    return (pi, pj, [ci[e, :sh[i][0] * sh[i][1]].view(*sh[i]) for e, (i, j) in enumerate(scene.edges)],
+            [cj[e, :sh[j][0] * sh[j][1]].view(*sh[j]) for e, (i, j) in enumerate(scene.edges)])
+
+
 def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
     """init_minimum_spanning_tree + init_from_pts3d (:69-126) on a mirror PointCloudOptimizer that is already on a device."""
     eng = scene._need_engine()
     dev = eng.device
-    H, W = scene.imshape
-    E, N = len(scene.edges), scene.n_imgs
-    pred_i, pred_j = eng.pred_i.reshape(E, H, W, 3), eng.pred_j.reshape(E, H, W, 3)
-    conf_i, conf_j = scene._raw_conf_i.to(dev), scene._raw_conf_j.to(dev)
+    E, N, P = len(scene.edges), scene.n_imgs, scene.max_area
+    pred_i, pred_j, conf_i, conf_j = edge_views(scene, dev)
     pts3d, _, im_focals, im_poses = minimum_spanning_tree(scene.imshapes, scene.edges, pred_i, pred_j, conf_i, conf_j, scene.im_conf,
                                                           scene.min_conf_thr, dev, init_priors=init_priors, verbose=scene.verbose)
     # ---- init_from_pts3d (:83-126); the known-poses branch (nkp > 1) re-aligns everything on the preset poses
@@ -299,9 +325,11 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
         pts3d = [geotrf(trf, p.reshape(-1, 3)).reshape(p.shape) for p in pts3d]
     pw = eng.params['pw_poses'].clone()
     # all E pairwise registrations pred_i[e] -> pts3d[i] in ONE launch of the moments kernel + one batched 3x3 SVD
-    sols = rigid_points_registration_batched(pred_i.reshape(E, H * W, 3).float().contiguous(),
-                                             torch.stack([p.reshape(H * W, 3) for p in pts3d]).float().contiguous(),
-                                             conf_i.reshape(E, H * W).float().contiguous(), [i for i, _ in scene.edges])
+    # (stacked buffers zero-filled to max_area; the padded tail carries zero confidence = zero weight)
+    pad = lambda t: torch.cat((t, t.new_zeros((P - len(t),) + tuple(t.shape[1:])))) if len(t) < P else t
+    sols = rigid_points_registration_batched(eng.pred_i.reshape(E, P, 3),
+                                             torch.stack([pad(p.reshape(-1, 3).float()) for p in pts3d]).contiguous(),
+                                             scene._raw_conf_i.to(dev).reshape(E, P).float().contiguous(), [i for i, _ in scene.edges])
     pw[:, 0:4] = torch.stack([rotmat_to_unitquat(R) for _, R, _ in sols]).to(dev)
     pw[:, 4:7] = signed_log1p(torch.stack([T / s for s, _, T in sols])).to(dev)
     pw[:, 7] = torch.tensor([float(np.log(s)) for s, _, _ in sols], device=dev)
@@ -317,7 +345,7 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
         if not scene.if_use_mono:
             w2c = torch.linalg.inv(c2w)
             d = geotrf(w2c, pts3d[i].reshape(-1, 3))[:, 2]
-            depth[i] = d.log().nan_to_num(neginf=0)
+            depth[i] = pad(d).log().nan_to_num(neginf=0)          # _set_depthmap: _ravel_hw zero-fill, log(0) -> 0
         if eng.flags['train_poses']:
             poses[i, 0:4] = rotmat_to_unitquat(c2w[:3, :3]).to(dev)
             poses[i, 4:7] = signed_log1p(c2w[:3, 3])
@@ -353,10 +381,9 @@ def init_from_known_poses(scene, niter_PnP=10, min_conf_thr=3):
         raise AssertionError('not all poses are known')
     if eng.flags['train_focals']:
         raise AssertionError('not all focals are known')          # the reference asserts nkf == n_imgs
-    H, W = scene.imshape
-    E = len(scene.edges)
-    pred_i, pred_j = eng.pred_i.reshape(E, H, W, 3), eng.pred_j.reshape(E, H, W, 3)
-    conf_i = scene._raw_conf_i.to(dev)
+    E, P = len(scene.edges), scene.max_area
+    pred_i, pred_j, conf_i, _ = edge_views(scene, dev)
+    pad = lambda t: torch.cat((t, t.new_zeros((P - len(t),) + tuple(t.shape[1:])))) if len(t) < P else t
     known_poses = scene.get_im_poses()
     im_focals = scene.get_focals().reshape(-1)
     im_pp = scene.get_principal_points()
@@ -380,5 +407,5 @@ def init_from_known_poses(scene, niter_PnP=10, min_conf_thr=3):
     if not scene.if_use_mono:
         for n in range(scene.n_imgs):
             _, e, s = best[n]
-            depth[n] = (pred_i[e][:, :, 2].reshape(-1) * s).log().nan_to_num(neginf=0)
+            depth[n] = pad(pred_i[e][:, :, 2].reshape(-1) * s).log().nan_to_num(neginf=0)
     eng.set_params(pw_poses=pw, depth=depth)

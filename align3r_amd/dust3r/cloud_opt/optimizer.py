@@ -7,8 +7,8 @@ im_poses [N,7], im_focals = focal_break*log f, im_pp), same random initial state
 (Adam betas (0.9, 0.9), cosine/linear schedule).  Gradients are analytic (the reference uses autograd).
 init='mst' is available but PARITY UNPINNED (init_im_poses.py of this package: roma / cv2 are absent).
 init='known_poses' and init='mst' on preset poses are available too (same caveat: the PnP is a linear stand-in for cv2's).
-Not available here (raise NotImplementedError): allow_pw_adaptors=True, images of different shapes in one problem (padding is
-supported by the kernels, see a3r.h, but not wired through this class yet).
+allow_pw_adaptors=True (gradient + Adam on pw_adaptors in the kernels) and images of different shapes in one problem (per-edge
+lists, every map zero-filled to max_area like _ravel_hw) are supported and pinned against reference goldens (tests/golden/alignx.npz).
 """
 from __future__ import annotations
 
@@ -34,52 +34,62 @@ class PointCloudOptimizer:
         self.dist = dist
         self.verbose = verbose
         self.if_use_mono = bool(if_use_mono)
-        if allow_pw_adaptors:
-            raise NotImplementedError('allow_pw_adaptors=True')
+        self.allow_pw_adaptors = bool(allow_pw_adaptors)            # base_opt.py:117-118: pw_adaptors.requires_grad_(allow_pw_adaptors)
         indices = sorted({i for e in self.edges for i in e})       # base_opt.py:164-167
         assert indices == list(range(len(indices))), 'bad pair indices: missing values '
         self.n_imgs = len(indices)
-        self._pred_i = torch.as_tensor(pred1['pts3d']).float()
-        self._pred_j = torch.as_tensor(pred2['pts3d_in_other_view']).float()
-        self.imshapes = get_imshapes(self.edges, self._pred_i, self._pred_j)
-        self._conf_i = torch.as_tensor(pred1['conf']).float()
-        self._conf_j = torch.as_tensor(pred2['conf']).float()
+        E, N = len(self.edges), self.n_imgs
+        # the predictions come as one tensor [E,H,W,3] (inference() on same-size pairs) or as per-edge lists (multiple shapes:
+        # inference() collates with lists=True, dust3r/inference.py:72)
+        as_f = lambda t: torch.as_tensor(t).float()
+        p_i, p_j = pred1['pts3d'], pred2['pts3d_in_other_view']
+        c_i, c_j = pred1['conf'], pred2['conf']
+        self.imshapes = get_imshapes(self.edges, p_i, p_j)
+        areas = [h * w for h, w in self.imshapes]
+        self.imshape = self.imshapes[0]                              # optimizer.py:41
+        self.max_area = P = max(areas)
+        self._uniform = all(s == self.imshapes[0] for s in self.imshapes)
+        if self._uniform and torch.is_tensor(p_i) and torch.is_tensor(p_j):
+            self._pred_i, self._pred_j = as_f(p_i).reshape(E, P, 3), as_f(p_j).reshape(E, P, 3)      # views: no copy
+            self._conf_i, self._conf_j = as_f(c_i).reshape(E, P), as_f(c_j).reshape(E, P)
+        else:
+            # _ravel_hw (optimizer.py:271-277): every map is flattened and zero-filled up to max_area
+            self._pred_i = torch.stack([_ravel_hw(as_f(p_i[e]), P) for e in range(E)])
+            self._pred_j = torch.stack([_ravel_hw(as_f(p_j[e]), P) for e in range(E)])
+            self._conf_i = torch.stack([_ravel_hw(as_f(c_i[e]), P) for e in range(E)])
+            self._conf_j = torch.stack([_ravel_hw(as_f(c_j[e]), P) for e in range(E)])
         self._raw_conf_i, self._raw_conf_j = self._conf_i.cpu(), self._conf_j.cpu()     # kept for the MST initialisation
         self.min_conf_thr = min_conf_thr
         self.conf_trf = get_conf_trf(conf)
         # per-image confidence = max over the edges it appears in (base_opt.py:169-175)
         im_conf = [torch.zeros(hw) for hw in self.imshapes]
         for e, (i, j) in enumerate(self.edges):
-            im_conf[i] = torch.maximum(im_conf[i], self._conf_i[e].cpu())
-            im_conf[j] = torch.maximum(im_conf[j], self._conf_j[e].cpu())
+            (hi, wi), (hj, wj) = self.imshapes[i], self.imshapes[j]
+            im_conf[i] = torch.maximum(im_conf[i], self._raw_conf_i[e, :hi * wi].view(hi, wi))
+            im_conf[j] = torch.maximum(im_conf[j], self._raw_conf_j[e, :hj * wj].view(hj, wj))
         self.im_conf = im_conf
         self.base_scale, self.pw_break, self.focal_break = base_scale, pw_break, focal_break
         self.norm_pw_scale = True
         self.rand_pose = rand_pose
         self.has_im_poses = True
-        H, W = self.imshapes[0]
-        if any(s != (H, W) for s in self.imshapes):
-            raise NotImplementedError('images of different shapes in one alignment problem')
-        self.imshape = (H, W)
-        self.max_area = H * W
-        E, N, P = len(self.edges), self.n_imgs, H * W
-        # ---- parameters, drawn in the reference's order (base_opt.py:116; optimizer.py:29-38)
-        init = dict(pw_poses=rand_pose((E, 1 + self.POSE_DIM)))
+        # ---- parameters, drawn in the reference's order (base_opt.py:116-117; optimizer.py:29-38)
+        init = dict(pw_poses=rand_pose((E, 1 + self.POSE_DIM)), pw_adaptors=torch.zeros(E, 2))
         if not self.if_use_mono:
-            init['depth'] = torch.stack([torch.randn(H, W) / 10 - 3 for _ in range(N)]).reshape(N, P)
+            init['depth'] = torch.stack([_ravel_hw(torch.randn(H, W) / 10 - 3, P) for H, W in self.imshapes])
             self.mono_depths = None
         else:
             init['depth'] = torch.zeros(N, P)
             init['shifts'] = torch.zeros(N)
-            self.mono_depths = torch.stack([torch.as_tensor(m).float().reshape(P) for m in mono_depths])
+            self.mono_depths = torch.stack([_ravel_hw(as_f(m).reshape(hw), P) for m, hw in zip(mono_depths, self.imshapes)])
         init['im_poses'] = torch.stack([rand_pose(self.POSE_DIM) for _ in range(N)])
-        init['im_focals'] = torch.full((N,), float(focal_break * np.log(max(H, W))))
+        init['im_focals'] = torch.tensor([float(focal_break * np.log(max(H, W))) for H, W in self.imshapes])
         self._init = init
-        self._flags = dict(train_poses=True, train_focals=True, train_pp=bool(optimize_pp))
-        self.total_area_i = sum(P for _ in self.edges)
-        self.total_area_j = self.total_area_i
+        self._flags = dict(train_poses=True, train_focals=True, train_pp=bool(optimize_pp), train_adaptors=self.allow_pw_adaptors)
+        self.total_area_i = sum(areas[i] for i, j in self.edges)         # optimizer.py:70-71
+        self.total_area_j = sum(areas[j] for i, j in self.edges)
         self.engine = None
         self.device = torch.device('cpu')
+        self._grid = None
         self.imgs = None
         if 'img' in view1 and 'img' in view2:
             imgs = [None] * N
@@ -96,26 +106,39 @@ class PointCloudOptimizer:
         if device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = device
-        E, P = len(self.edges), self.max_area
         state = self._current_state()          # a repeated .to() keeps the parameter values (nn.Module.to semantics)
-        w_i = self.conf_trf(self._conf_i).reshape(E, P)
-        w_j = self.conf_trf(self._conf_j).reshape(E, P)
-        self.engine = AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i.reshape(E, P, 3),
-                                  self._pred_j.reshape(E, P, 3), w_i, w_j, self.imshapes, mono=self.mono_depths,
-                                  base_scale=self.base_scale, pw_break=self.pw_break, focal_break=self.focal_break,
-                                  norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device, **self._flags)
+        self.engine = self._build_engine(device)
         self.engine.set_params(**(state or self._init))
         # keep handles on the engine's device tensors instead of the (possibly host) originals: no second copy stays alive, and
         # .to() can be called again like nn.Module.to (the confidences are re-derived from the raw host copies)
         self._pred_i, self._pred_j = self.engine.pred_i, self.engine.pred_j
         self._conf_i, self._conf_j = self._raw_conf_i, self._raw_conf_j
+        self._grid = None
         return self
+
+    def _stacked_weights(self):
+        E, P = len(self.edges), self.max_area
+        out = []
+        for conf, side in ((self._conf_i, 0), (self._conf_j, 1)):
+            w = self.conf_trf(conf)
+            if not self._uniform:
+                area = torch.tensor([self.imshapes[e[side]][0] * self.imshapes[e[side]][1] for e in self.edges], device=w.device)
+                pad = torch.arange(P, device=w.device)[None, :] >= area[:, None]
+                w = w.masked_fill(pad, 0.0)
+            out.append(w.reshape(E, P))
+        return out
+
+    def _build_engine(self, device):
+        w_i, w_j = self._stacked_weights()
+        return AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i, self._pred_j, w_i, w_j,
+                           self.imshapes, mono=self.mono_depths, base_scale=self.base_scale, pw_break=self.pw_break,
+                           focal_break=self.focal_break, norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device, **self._flags)
 
     def _current_state(self):
         """Parameter values of the live engine (host copies), or None before the first .to()."""
         if self.engine is None:
             return None
-        keys = ['pw_poses', 'depth', 'im_poses', 'im_focals', 'im_pp', 'pw_adaptors'] + (['shifts'] if self.if_use_mono else [])
+        keys = ['pw_poses', 'pw_adaptors', 'depth', 'im_poses', 'im_focals', 'im_pp'] + (['shifts'] if self.if_use_mono else [])
         return {k: self.engine.params[k].detach().cpu().clone() for k in keys}
 
     def _need_engine(self):
@@ -139,6 +162,10 @@ class PointCloudOptimizer:
     @property
     def pw_poses(self):
         return self._need_engine().params['pw_poses']
+
+    @property
+    def pw_adaptors(self):
+        return self._need_engine().params['pw_adaptors']
 
     @property
     def im_poses(self):
@@ -177,6 +204,13 @@ class PointCloudOptimizer:
         RT[:, :3, 3] = T
         RT[:, 3, 3] = 1
         return RT
+
+    def get_adaptors(self):
+        adapt = self.pw_adaptors                                     # base_opt.py:177-182
+        adapt = torch.cat((adapt[:, 0:1], adapt), dim=-1)            # (scale_xy, scale_xy, scale_z)
+        if self.norm_pw_scale:
+            adapt = adapt - adapt.mean(dim=1, keepdim=True)
+        return (adapt / self.pw_break).exp()
 
     def get_pw_norm_scale_factor(self):
         if self.norm_pw_scale:
@@ -221,11 +255,19 @@ class PointCloudOptimizer:
             res = [dm[:h * w].view(h, w) for dm, (h, w) in zip(res, self.imshapes)]
         return res
 
+    def _pixel_grid(self):
+        """_grid of optimizer.py:55-56: xy pixel grid of every image, zero-filled up to max_area [N,P,2]."""
+        if self._grid is None or self._grid.device != self.device:
+            grids = []
+            for H, W in self.imshapes:
+                ys, xs = torch.meshgrid(torch.arange(H, device=self.device), torch.arange(W, device=self.device), indexing='ij')
+                grids.append(_ravel_hw(torch.stack((xs, ys), -1).float(), self.max_area))
+            self._grid = torch.stack(grids)
+        return self._grid
+
     def depth_to_pts3d(self):
-        H, W = self.imshape
         depth = self.get_depthmaps(raw=True)                                   # [N,P]
-        ys, xs = torch.meshgrid(torch.arange(H, device=self.device), torch.arange(W, device=self.device), indexing='ij')
-        grid = torch.stack((xs, ys), -1).reshape(1, H * W, 2).float()
+        grid = self._pixel_grid()
         pp = self.get_principal_points()[:, None]
         f = self.get_focals()[:, None]
         rel = torch.cat((depth[..., None] * (grid - pp) / f, depth[..., None]), -1)
@@ -328,8 +370,8 @@ class PointCloudOptimizer:
     def preset_principal_point(self, known_pp, msk=None):
         self._check_all(msk)
         pp = self.im_pp.clone()
-        H, W = self.imshape
         for idx, p in zip(self._msk_indices(msk), known_pp):
+            H, W = self.imshapes[idx]
             pp[idx] = (torch.as_tensor(p, dtype=torch.float32).to(pp.device) - torch.tensor([W / 2, H / 2], device=pp.device)) / 10
         self._flags['train_pp'] = False
         self.engine.flags.update(train_pp=False)
@@ -366,6 +408,14 @@ class PointCloudOptimizer:
         if self.verbose:
             print(f'Global alignement - {niter} iterations, final lr={lr_min if niter > 1 else lr:g} loss={losses[-1]:g}')
         return float(losses[-1])
+
+
+def _ravel_hw(tensor, fill=0):
+    """Flatten the two leading (H, W) axes and zero-fill up to `fill` rows (optimizer.py:271-277)."""
+    tensor = tensor.reshape((tensor.shape[0] * tensor.shape[1],) + tuple(tensor.shape[2:]))
+    if len(tensor) < fill:
+        tensor = torch.cat((tensor, tensor.new_zeros((fill - len(tensor),) + tuple(tensor.shape[1:]))))
+    return tensor
 
 
 def clean_pointcloud(im_confs, K, cams, depthmaps, all_pts3d, tol=0.001, bad_conf=0, dbg=()):

@@ -103,26 +103,16 @@ class PointCloudOptimizer(_Base):
             acc[j].append(err_j[e])
         self.dynamic_masks = [(torch.stack(a).mean(dim=0) > self.motion_mask_thre).cpu() for a in acc]
 
-    def to(self, device):
-        device = torch.device(device)
-        if device.type != 'cuda':
-            raise RuntimeError('PointCloudOptimizer: this build has no CPU compute path; pass a HIP device ("cuda")')
-        if device.index is None:
-            device = torch.device('cuda', torch.cuda.current_device())
-        self.device = device
-        E, P = len(self.edges), self.max_area
-        state = self._current_state()          # a repeated .to() keeps the parameter values (nn.Module.to semantics)
-        self.engine = AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i.reshape(E, P, 3),
-                                  self._pred_j.reshape(E, P, 3), self.conf_trf(self._conf_i).reshape(E, P),
-                                  self.conf_trf(self._conf_j).reshape(E, P), self.imshapes, mono=None,
-                                  base_scale=self.base_scale, pw_break=self.pw_break, focal_break=self.focal_break,
-                                  norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device,
-                                  shared_focal=self.shared_focal, temporal_smoothing_weight=float(self.temporal_smoothing_weight),
-                                  translation_weight=float(self.translation_weight), flow=self._flow, **self._flags)
-        self.engine.set_params(**(state or self._init))
-        self._pred_i, self._pred_j = self.engine.pred_i, self.engine.pred_j
-        self._conf_i, self._conf_j = self._raw_conf_i, self._raw_conf_j
-        return self
+    def _build_engine(self, device):
+        """The base class's .to() with the flow variant's extras (shared focal, temporal smoothing, ego-flow inputs)."""
+        if not self._uniform and self._flow is not None:
+            raise RuntimeError('the flow term needs images of one shape (flow fields are stacked [E,2,H,W], optimizer.py:118-154)')
+        w_i, w_j = self._stacked_weights()
+        return AlignEngine([i for i, j in self.edges], [j for i, j in self.edges], self._pred_i, self._pred_j, w_i, w_j,
+                           self.imshapes, mono=None, base_scale=self.base_scale, pw_break=self.pw_break,
+                           focal_break=self.focal_break, norm_pw_scale=self.norm_pw_scale, dist=self.dist, device=device,
+                           shared_focal=self.shared_focal, temporal_smoothing_weight=float(self.temporal_smoothing_weight),
+                           translation_weight=float(self.translation_weight), flow=self._flow, **self._flags)
 
     @property
     def im_focals(self):

@@ -426,6 +426,82 @@ def gen_align(out):
         json.dump(meta, f)
 
 
+def gen_alignx(out):
+    """PointCloudOptimizer beyond the uniform stacked case:
+      * 'mixed': images of DIFFERENT shapes in one problem -- per-edge lists, every map zero-filled to max_area by _ravel_hw
+        (optimizer.py:55-71,271-277), per-image grids / focals / areas;
+      * 'adapt': allow_pw_adaptors=True (base_opt.py:117-118,177-182) -- pw_adaptors trainable;
+      * 'mixed_adapt_mono': both, with the mono-depth parameterisation.
+    Captured like gen_align: initial state, autograd gradients of the first evaluation, states after 1/5/50 iterations."""
+    from dust3r.cloud_opt import global_aligner, GlobalAlignerMode
+    from dust3r.cloud_opt.base_opt import global_alignment_iter
+    meta = dict(note="roma stand-in: closed-form XYZW unit-quaternion -> 4x4 (see module docstring)", cases=[])
+    g = {}
+    cases = [("mixed", [(16, 24), (16, 24), (12, 20), (20, 16)], False, False, "cosine", 0.05),
+             ("adapt", [(16, 24)] * 4, True, False, "cosine", 0.05),
+             ("mixed_adapt_mono", [(12, 16), (16, 12), (10, 20)], True, True, "linear", 0.02)]
+    for tag, shapes, adapt, use_mono, sched, lr in cases:
+        N = len(shapes)
+        edges = [(i, j) for i in range(N) for j in range(N) if i != j]
+        E = len(edges)
+        rng = np.random.default_rng(13)
+        p1 = [rng.standard_normal(shapes[i] + (3,)).astype(np.float32) for i, j in edges]
+        p2 = [rng.standard_normal(shapes[j] + (3,)).astype(np.float32) for i, j in edges]
+        c1 = [(1 + 9 * rng.random(shapes[i])).astype(np.float32) for i, j in edges]
+        c2 = [(1 + 9 * rng.random(shapes[j])).astype(np.float32) for i, j in edges]
+        mono = [(0.5 + 3 * rng.random(hw)).astype(np.float32) for hw in shapes]
+        tt = lambda lst: [torch.from_numpy(a) for a in lst]
+        output = dict(view1=dict(idx=[i for i, j in edges]), view2=dict(idx=[j for i, j in edges]),
+                      pred1=dict(pts3d=tt(p1), conf=tt(c1)), pred2=dict(pts3d_in_other_view=tt(p2), conf=tt(c2)))
+        torch.manual_seed(17)
+        net = global_aligner(output, use_mono, tt(mono) if use_mono else [], "cpu", mode=GlobalAlignerMode.PointCloudOptimizer,
+                             verbose=False, min_conf_thr=3, allow_pw_adaptors=adapt)
+        with torch.no_grad():
+            if adapt:      # a non-trivial starting point for the adaptors (they initialise at 0)
+                net.pw_adaptors.copy_(0.5 * torch.randn_like(net.pw_adaptors))
+            if use_mono:
+                net.scalemaps.copy_(0.1 * torch.randn_like(net.scalemaps))
+                net.shifts.copy_(0.05 * torch.randn_like(net.shifts))
+        for e in range(E):
+            g[f"{tag}_p1_{e}"], g[f"{tag}_p2_{e}"], g[f"{tag}_c1_{e}"], g[f"{tag}_c2_{e}"] = p1[e], p2[e], c1[e], c2[e]
+        if use_mono:
+            for n in range(N):
+                g[f"{tag}_mono_{n}"] = mono[n]
+        trainable = [n for n, p in net.named_parameters() if p.requires_grad]
+        for n, p in net.named_parameters():
+            if n in trainable or n in ("im_pp", "pw_adaptors"):
+                g[f"{tag}_init_{n}"] = p.detach().numpy().copy()
+        with torch.no_grad():
+            g[f"{tag}_pw_poses_4x4"] = net.get_pw_poses().numpy()
+            g[f"{tag}_adaptors"] = net.get_adaptors().numpy()
+            g[f"{tag}_pts3d0"] = net.get_pts3d(raw=True).numpy()
+        loss0 = net()
+        loss0.backward()
+        g[f"{tag}_loss0"] = np.float64(loss0.item())
+        for n, p in net.named_parameters():
+            if n in trainable:
+                g[f"{tag}_grad_{n}"] = p.grad.numpy().copy()
+                p.grad = None
+        niter = 50
+        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=lr, betas=(0.9, 0.9))
+        losses = []
+        for it in range(niter):
+            loss, _ = global_alignment_iter(net, it, niter, lr, 1e-6, opt, sched)
+            losses.append(loss)
+            if it + 1 in (1, 5, 50):
+                for n, p in net.named_parameters():
+                    if n in trainable:
+                        g[f"{tag}_k{it+1}_{n}"] = p.detach().numpy().copy()
+        g[f"{tag}_losses"] = np.asarray(losses, np.float64)
+        meta["cases"].append(dict(tag=tag, shapes=shapes, allow_pw_adaptors=adapt, use_mono=use_mono, schedule=sched, lr=lr,
+                                  lr_min=1e-6, niter=niter, edges=edges, trainable=trainable,
+                                  total_area_i=int(net.total_area_i), total_area_j=int(net.total_area_j)))
+        print("alignx", tag, "loss0", float(loss0), "->", losses[-1], "trainable", trainable)
+    np.savez_compressed(os.path.join(out, "alignx.npz"), **g)
+    with open(os.path.join(out, "alignx.json"), "w") as f:
+        json.dump(meta, f)
+
+
 def _flow_scene(N, H, W, seed):
     """Geometric scene in the aligner's own conventions (integer pixel grid, pp = (W/2, H/2)): per-frame depth,
     camera-to-world poses, pairwise pointmaps, ground-truth ego-flow between frames (+ noise and gross outliers),

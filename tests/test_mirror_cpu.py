@@ -106,3 +106,36 @@ def test_aligner_initial_state_matches_reference_for_same_seed():
     with pytest.raises(AssertionError, match="bad pair indices"):
         PointCloudOptimizer(bad, dict(idx=[2, 0]), dict(pts3d=torch.zeros(2, 4, 4, 3), conf=torch.ones(2, 4, 4)),
                             dict(pts3d_in_other_view=torch.zeros(2, 4, 4, 3), conf=torch.ones(2, 4, 4)), False, [])
+
+
+def test_pointcloud_optimizer_mixed_shapes_host_logic():
+    """Host side of row a-11 without a GPU: per-edge lists of different shapes are zero-filled to max_area like _ravel_hw
+    (optimizer.py:271-277), areas / focals are per image, and the same torch seed draws the reference's initial state
+    (tests/golden/alignx.npz holds the reference's own parameters for this scene)."""
+    import json
+    import numpy as np
+    import torch
+    from conftest import GOLDEN
+    from align3r_amd.dust3r.cloud_opt.optimizer import PointCloudOptimizer
+    g = np.load(os.path.join(GOLDEN, "alignx.npz"))
+    case = json.load(open(os.path.join(GOLDEN, "alignx.json")))["cases"][0]
+    tag, edges = case["tag"], [tuple(e) for e in case["edges"]]
+    E = len(edges)
+    tt = lambda key: [torch.from_numpy(g[f"{tag}_{key}_{e}"]) for e in range(E)]
+    torch.manual_seed(17)
+    opt = PointCloudOptimizer(dict(idx=[i for i, j in edges]), dict(idx=[j for i, j in edges]), dict(pts3d=tt("p1"), conf=tt("c1")),
+                              dict(pts3d_in_other_view=tt("p2"), conf=tt("c2")), False, [], verbose=False)
+    assert [tuple(s) for s in opt.imshapes] == [tuple(s) for s in case["shapes"]]
+    P = max(h * w for h, w in case["shapes"])
+    assert opt.max_area == P and opt._pred_i.shape == (E, P, 3) and not opt._uniform
+    assert opt.total_area_i == case["total_area_i"] and opt.total_area_j == case["total_area_j"]
+    for e, (i, j) in enumerate(edges):
+        hi, wi = case["shapes"][i]
+        assert torch.equal(opt._pred_i[e, :hi * wi], tt("p1")[e].reshape(-1, 3)) and not opt._pred_i[e, hi * wi:].any()
+    w_i, w_j = opt._stacked_weights()
+    hj, wj = case["shapes"][edges[0][1]]
+    assert torch.equal(w_j[0, :hj * wj], tt("c2")[0].reshape(-1).log()) and not w_j[0, hj * wj:].any()      # log of the real pixels, 0 on the tail
+    assert np.array_equal(opt._init["pw_poses"].numpy(), g[f"{tag}_init_pw_poses"])
+    assert np.array_equal(opt._init["depth"].numpy(), g[f"{tag}_init_im_depthmaps"])
+    assert np.array_equal(opt._init["im_poses"].numpy(), g[f"{tag}_init_im_poses"])
+    assert np.allclose(opt._init["im_focals"].numpy(), g[f"{tag}_init_im_focals"].ravel())
