@@ -28,6 +28,7 @@ constexpr int PXT = 4;                 // pixels per thread
 constexpr int TPB = 256;
 constexpr int CHUNK = PXT * TPB;       // pixels per workgroup
 constexpr int EB = 8;                  // (edge,side) entries per LDS reduction batch
+constexpr int MAX_INC = 2048;          // edge sides incident to one image (their codes sit in LDS: 8 KB)
 constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.9f, ADAM_EPS = 1e-8f;  // base_opt.py:435
 
 struct AlignDev {
@@ -173,6 +174,9 @@ template <bool VEC> struct EdgeData;
 template <> struct EdgeData<true> { f32x4 a, b, c, w; };                    // 4 consecutive pixels: xyz xyz xyz xyz, wwww
 template <> struct EdgeData<false> { float x[PXT][3]; float w[PXT]; };
 
+// (Inline-asm loads with hand-placed counted waits were tried here to keep TWO edge sides per wave in flight -- hipcc's waitcnt
+// pass puts a vmcnt wait in front of the next buffer's loads -- and abandoned: the register allocator copies the asm loads'
+// destination registers at the loop's phi points while the data may still be landing, which no source-level form prevents.)
 __device__ __forceinline__ void load_edge(const AlignDev& d, int code, int P, int pix0, const bool* valid, EdgeData<true>& o) {
     const int e = code >> 1, side = code & 1;
     const float* X = (side ? d.pred_j : d.pred_i) + (size_t)e * P * 3;
@@ -209,20 +213,28 @@ __device__ __forceinline__ void unpack_edge(const EdgeData<false>& e, float (*x)
 struct TailOut { float *g_pw, *g_small, *loss_out, *g_adapt; };
 __device__ void edge_chain(const AlignDev& d, int e, const double* s, bool loss_only);
 __device__ void image_chain(const AlignDev& d, int n, double* s);
-__device__ __forceinline__ void wave_sum_rows(const float* base, int nchunks, int lane, float* tot);
+__device__ __forceinline__ f32x4 wave_sum_rows(const float* base, int nchunks, int lane);
 template <int MODE>
 __device__ void finalize_b_body(const AlignDev& d, const AdamArgs& ad, const TailOut& o, float* sh, double (*shd)[4]);
 
-// Arrival of this workgroup on a ticket counter after its global stores (MI355X guide, Guideline 16 counter form): every storing
-// wave drains its stores, the workgroup meets, ONE lane releases at agent scope and draws a ticket; the workgroup that draws the
-// last ticket acquires at agent scope before any of its threads reads what the others stored.  Returns (to every thread) whether
-// this workgroup is that last one.  `flag` is one int of LDS.
+// Arrival of this workgroup on a ticket counter after its hand-off stores (MI355X guide, Guideline 16, write-through form).
+// Producer side: EVERY handed-off byte is stored write-through at agent scope (store_wt below = global_store ... sc1), so no
+// release fence -- which would write back the whole XCD L2, all the parameter / Adam lines of this iteration included, once per
+// workgroup (measured: 280 us per iteration instead of 150) -- is needed: every storing wave drains its stores, the workgroup
+// meets, ONE lane draws a ticket.  Consumer side: the workgroup that draws the last ticket acquires at agent scope (one
+// buffer_inv, by one lane, then the barrier) before any of its threads reads what the others stored.
+// Returns (to every thread) whether this workgroup is that last one.  `flag` is one int of LDS.
+// 16 bytes per lane: a dword-wide sc1 store is one fabric write EACH (measured here: +26 us per iteration at E = 84, +120 us at
+// E = 992 when the partial rows went out as 13 dword stores), a dwordx4 one costs what a plain store costs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(float* base /* wave-uniform */, unsigned off_bytes, f32x4 v) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)off_bytes, 0, 16);   // aux 16 = sc1
+}
 __device__ __forceinline__ bool arrive_last(int* counter, int expected, int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // never let the ticket overtake the write-back (compiler hazard)
         const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old == expected - 1;
         if (last) {
@@ -383,34 +395,46 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
     };
 
     const int kbeg = inc_ptr[n], kend = inc_ptr[n + 1];
+    // The image's incidence codes go to LDS once: read from global memory inside the loop they are VECTOR loads (hipcc does not
+    // prove them uniform), and the s_waitcnt vmcnt(0) each one needs before its value can form the next address drains the
+    // edge data prefetched into the other register buffer -- one edge side in flight instead of two.  An LDS read waits on
+    // lgkmcnt and leaves the vector-memory queue alone; readfirstlane keeps the address arithmetic on the scalar unit.
+    // (a3r_align_create rejects graphs with more than MAX_INC edge sides per image)
+    __shared__ int s_inc[MAX_INC];
+    for (int i = tid; i < kend - kbeg; i += TPB) s_inc[i] = inc[kbeg + i];
+    __syncthreads();
+    auto code_at = [&](int k) { return __builtin_amdgcn_readfirstlane(s_inc[k - kbeg]); };
     int buf = 0;
     EdgeData<VEC> ea, eb;
-    if (kbeg < kend) load_edge(d, inc[kbeg], P, pix0, valid, ea);
-    for (int k0 = kbeg; k0 < kend; k0 += EB) {
+    if (kbeg < kend) load_edge(d, code_at(kbeg), P, pix0, valid, ea);
+    // one flat loop, two edge sides per trip; the LDS batch of EB slots is flushed inside
+    int kb = 0, k0 = kbeg;
 #pragma unroll 1
-        for (int kb = 0; kb < EB; kb += 2) {
-            const int k = k0 + kb;
-            if (k >= kend) break;
-            const int code0 = inc[k];
-            const bool has1 = k + 1 < kend;
-            const int code1 = has1 ? inc[k + 1] : code0;
-            if (has1) load_edge(d, code1, P, pix0, valid, eb);          // in flight while `ea` is consumed
-            consume(code0, ea, buf, kb);
-            if (!has1) break;
-            if (k + 2 < kend) load_edge(d, inc[k + 2], P, pix0, valid, ea);
+    for (int k = kbeg; k < kend; k += 2) {
+        const int code0 = code_at(k);
+        const bool has1 = k + 1 < kend;
+        const int code1 = has1 ? code_at(k + 1) : code0;
+        if (has1) load_edge(d, code1, P, pix0, valid, eb);          // in flight while `ea` is consumed
+        consume(code0, ea, buf, kb);
+        if (has1) {
+            if (k + 2 < kend) load_edge(d, code_at(k + 2), P, pix0, valid, ea);
             consume(code1, eb, buf, kb + 1);
         }
-        __syncthreads();
-        if (tid < EB * 16) {
-            const int kb = tid >> 4, j = tid & 15, k = k0 + kb;
-            if (k < kend && j < 13) {
-                float s = 0.f;
+        kb += 2;
+        if (kb == EB || k + 2 >= kend) {
+            __syncthreads();
+            if (tid < EB * 4) {
+                // one 16-byte quarter of a slot's row per thread, rows r added in order (the row is handed to the image's last workgroup)
+                const int sb = tid >> 2, q = tid & 3, ks = k0 + sb;
+                if (ks < kend) {
+                    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 16; r++) s += red[buf][kb][r][j];
-                d.partE[((size_t)k * d.nchunks + chunk) * 16 + j] = s;
+                    for (int r = 0; r < 16; r++) s4 += *reinterpret_cast<const f32x4*>(&red[buf][sb][r][4 * q]);
+                    store16_wt(d.partE, (unsigned)(((size_t)ks * d.nchunks + chunk) * 64 + 16 * q), s4);
+                }
             }
+            buf ^= 1; kb = 0; k0 += EB;
         }
-        buf ^= 1;
     }
     if (MODE != 0) {
 
@@ -484,11 +508,11 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
         if ((lane & 15) == 0) red[0][0][wave * 4 + (lane >> 4)][j] = s;
     }
     __syncthreads();
-    if (tid < 16) {
-        float s = 0.f;
+    if (tid < 4) {
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; r++) s += red[0][0][r][tid];
-        d.partN[((size_t)n * d.nchunks + chunk) * 16 + tid] = s;
+        for (int r = 0; r < 16; r++) s4 += *reinterpret_cast<const f32x4*>(&red[0][0][r][4 * tid]);
+        store16_wt(d.partN, (unsigned)(((size_t)n * d.nchunks + chunk) * 64 + 16 * tid), s4);
     }
     }   // MODE != 0
     if (!d.fused_tail) return;
@@ -499,16 +523,13 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
     __syncthreads();                                   // red[] is free again
     int* flag = reinterpret_cast<int*>(&red[0][0][0][0]);
     if (!arrive_last(d.tick + n, gridDim.x, flag)) return;
-    {
-        float tot[16];
-        for (int k = kbeg + wave; k < kend; k += TPB / 64) {
-            wave_sum_rows(d.partE + (size_t)k * d.nchunks * 16, d.nchunks, lane, tot);
-            if (lane < 16) d.sumE[k * 16 + lane] = tot[lane];
-        }
-        if (MODE != 0 && wave == 0) {
-            wave_sum_rows(d.partN + (size_t)n * d.nchunks * 16, d.nchunks, lane, tot);
-            if (lane < 16) d.sumN[n * 16 + lane] = tot[lane];
-        }
+    for (int k = kbeg + wave; k < kend; k += TPB / 64) {
+        const f32x4 t = wave_sum_rows(d.partE + (size_t)k * d.nchunks * 16, d.nchunks, lane);
+        if (lane < 4) store16_wt(d.sumE, (unsigned)(k * 64 + 16 * lane), t);
+    }
+    if (MODE != 0 && wave == 0) {
+        const f32x4 t = wave_sum_rows(d.partN + (size_t)n * d.nchunks * 16, d.nchunks, lane);
+        if (lane < 4) store16_wt(d.sumN, (unsigned)(n * 64 + 16 * lane), t);
     }
     // Level 2: the workgroup that completes the last image runs the chain rules of all edges and images, then the single-block
     // finalisation (scale coupling, loss, Adam on the small parameters, next iteration's transforms).
@@ -868,14 +889,25 @@ __device__ void image_chain(const AlignDev& d, int n, double* s) {
     for (int k = 11; k < 16; k++) g[k] = 0.f;
 }
 
-// One wave: fixed-order sum of the nchunks 16-float partial rows at `base`; every lane returns the 16 totals in tot[].
-// lane = 4 c' + q reads floats [4q, 4q+4) of chunks c', c' + 16, ... (16-byte loads), then the 16 lanes that share q are
-// added by xor-shuffles (4, 8, 16, 32): the order never depends on which wave or workgroup runs it.
-__device__ __forceinline__ void wave_sum_rows(const float* base, int nchunks, int lane, float* tot /*[16]*/) {
+// One wave: fixed-order sum of the nchunks 16-float partial rows at `base`.  lane = 4 c' + q reads floats [4q, 4q+4) of chunks
+// c', c' + 16, ... (16-byte loads, eight in flight: the rows come from memory, not from this XCD's L2), then the 16 lanes that
+// share q are added by xor-shuffles (4, 8, 16, 32): the order never depends on which wave or workgroup runs it.
+// Returns, in every lane, the totals of floats [4q, 4q+4) with q = lane & 3.
+__device__ __forceinline__ f32x4 wave_sum_rows(const float* base, int nchunks, int lane) {
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
     const int q = lane & 3;
     const f32x4* pe = reinterpret_cast<const f32x4*>(base);
-    for (int c = lane >> 2; c < nchunks; c += 16) part += pe[c * 4 + q];
+    for (int c0 = lane >> 2; c0 < nchunks; c0 += 16 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int c = c0 + 16 * u;
+            v[u] = pe[(c < nchunks ? c : c0) * 4 + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (c0 + 16 * u < nchunks) part += v[u];
+    }
     float pv[4] = {part.x, part.y, part.z, part.w};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -883,6 +915,12 @@ __device__ __forceinline__ void wave_sum_rows(const float* base, int nchunks, in
         v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
         pv[t] = v;
     }
+    const f32x4 r = {pv[0], pv[1], pv[2], pv[3]};
+    return r;
+}
+// the 16 totals in every lane (float j lives in element j & 3 of lane j >> 2)
+__device__ __forceinline__ void quad_to_all(f32x4 t, float* tot /*[16]*/) {
+    const float pv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int j = 0; j < 16; j++) tot[j] = __shfl(pv[j & 3], j >> 2);
 }
@@ -892,8 +930,8 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
     const int b = blockIdx.x, lane = threadIdx.x;
     float t0[16], t1[16];
     if (b < d.E) {
-        wave_sum_rows(d.partE + (size_t)d.slot_of[b * 2 + 0] * d.nchunks * 16, d.nchunks, lane, t0);
-        wave_sum_rows(d.partE + (size_t)d.slot_of[b * 2 + 1] * d.nchunks * 16, d.nchunks, lane, t1);
+        quad_to_all(wave_sum_rows(d.partE + (size_t)d.slot_of[b * 2 + 0] * d.nchunks * 16, d.nchunks, lane), t0);
+        quad_to_all(wave_sum_rows(d.partE + (size_t)d.slot_of[b * 2 + 1] * d.nchunks * 16, d.nchunks, lane), t1);
         if (lane == 0) {
             double s[13];
             for (int j = 0; j < 13; j++) s[j] = (double)t0[j] + (double)t1[j];
@@ -901,7 +939,7 @@ __global__ __launch_bounds__(64) void align_finalize_a_kernel(AlignDev d, int lo
         }
     } else {
         const int n = b - d.E;
-        wave_sum_rows(d.partN + (size_t)n * d.nchunks * 16, d.nchunks, lane, t0);
+        quad_to_all(wave_sum_rows(d.partN + (size_t)n * d.nchunks * 16, d.nchunks, lane), t0);
         if (lane == 0) {
             double s[16];
             for (int j = 0; j < 16; j++) s[j] = (double)t0[j];
@@ -1076,6 +1114,8 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
         deg[i + 1]++; deg[j + 1]++; seen[i] = seen[j] = 1;
     }
     for (int n = 0; n < s->N; n++) A3R_CHECK_ARG(seen[n], "bad pair indices: missing values (image %d has no edge)", n);
+    for (int n = 0; n < s->N; n++)
+        A3R_CHECK_ARG(deg[n + 1] <= MAX_INC, "a3r_align_create: image %d has %d incident edge sides (limit %d)", n, deg[n + 1], MAX_INC);
     for (int n = 0; n < s->N; n++) {
         A3R_CHECK_ARG(s->imarea_host[n] > 0 && s->imarea_host[n] <= s->P && s->imw_host[n] > 0,
                       "a3r_align_create: bad image shape for image %d", n);
@@ -1127,8 +1167,13 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     d.sumE = (float*)(ws + off[13]); d.sumN = (float*)(ws + off[14]); d.tick = (int*)(ws + off[15]);
     d.order = (const int*)(ws + off[16]);
     {
-        const char* t = getenv("A3R_ALIGN_TAIL");       // developer A/B switch: "launch" = the separate finalize launches
-        d.fused_tail = (t && !strcmp(t, "launch")) ? 0 : 1;
+        // A3R_ALIGN_TAIL=fused: finish the iteration inside the main launch (last-block-done tickets) instead of the two small
+        // finalize launches.  Correct and bitwise identical, but measured SLOWER on MI355X (config 2: 147 vs 124 + 18 us per
+        // iteration; E = 992: 1005 vs 890 + 46 us): what the tail costs is its serial critical path -- the last image's partial
+        // rows, the edge chain rules, the single-block Adam -- not the two launch boundaries, so the
+        // separate launches, whose E + N workgroups reduce in parallel, stay the default.
+        const char* t = getenv("A3R_ALIGN_TAIL");
+        d.fused_tail = (t && !strcmp(t, "fused")) ? 1 : 0;
     }
     d.inc_ptr = (const int*)(ws + off[7]); d.inc = (const int*)(ws + off[8]); d.slot_of = (const int*)(ws + off[9]);
     d.imw = (const int*)(ws + off[10]); d.imarea = (const int*)(ws + off[11]);

@@ -259,26 +259,36 @@ def main():
         wi = torch.log(1 + 9 * torch.rand(E, P, generator=g))
         wj = torch.log(1 + 9 * torch.rand(E, P, generator=g))
         al = AlignEngine([i for i, j in edges], [j for i, j in edges], pi, pj, wi, wj, [(H, W)] * N, device=dev,
-                         loss_capacity=a.align_iters + 16)
+                         loss_capacity=2 * a.align_iters + 16)
         al.set_params(pw_poses=torch.randn(E, 8, generator=g), depth=torch.randn(N, P, generator=g) / 10 - 3,
                       im_poses=torch.randn(N, 7, generator=g), im_focals=torch.full((N,), 20 * float(np.log(max(H, W)))))
-        al.run(5, 0.05, "cosine", total_iters=a.align_iters + 5)
+        al.run(5, 0.05, "cosine", total_iters=2 * a.align_iters + 5)
         barrier()
-        _lib.prof_enable(True)
+        # (1) the iteration rate, un-profiled (the HIP events of the per-kernel profiler cost a few us per launch)
         t0 = time.perf_counter()
-        al.run(a.align_iters, 0.05, "cosine", first_iter=5, total_iters=a.align_iters + 5)
+        al.run(a.align_iters, 0.05, "cosine", first_iter=5, total_iters=2 * a.align_iters + 5)
         torch.cuda.synchronize()
         dta = time.perf_counter() - t0
+        # (2) the same again with HIP events around every launch: per-kernel durations for the roofline
+        _lib.prof_enable(True)
+        al.run(a.align_iters, 0.05, "cosine", first_iter=5 + a.align_iters, total_iters=2 * a.align_iters + 5)
+        torch.cuda.synchronize()
         _lib.prof_enable(False)
         pbn = {p["name"]: p for p in _lib.prof_report()}
-        pa = pbn["align_main_kernel"]
+        pa, ps = pbn["align_main_kernel"], pbn["align_finalize/prep kernels"]
         gbs = pa["work"] / (pa["ms"] * 1e-3) / 1e9 if pa["ms"] > 0 else 0.0
+        bytes_iter = pa["work"] / max(pa["launches"], 1)
+        it_gbs = bytes_iter * (a.align_iters / dta) / 1e9
         res["align_iters_per_s"] = round(a.align_iters / dta, 2)
         res["align_config"] = {"N": N, "E": E, "P": P, "use_mono": False, "iters": a.align_iters}
         res["roofline_align"] = {"bound": "hbm", "kernel": "align_main_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                  "traffic": pmc_traffic("align_main_kernel")[0] if (a.frames, E, P) == (16, 84, 196608) else None,
-                                 "bytes_per_iter": pa["work"] / max(pa["launches"], 1), "avg_launch_us": round(1e3 * pa["ms"] / max(pa["launches"], 1), 2)}
+                                 "bytes_per_iter": bytes_iter, "avg_launch_us": round(1e3 * pa["ms"] / max(pa["launches"], 1), 2),
+                                 "finalize_launches_us_per_iter": round(1e3 * ps["ms"] / max(pa["launches"], 1), 2),
+                                 "iteration": {"achieved": round(it_gbs, 1), "frac": round(it_gbs / PEAK_HBM_GBS, 4),
+                                               "us_per_iter": round(1e6 * dta / a.align_iters, 2),
+                                               "note": "whole iteration (main kernel + the two finalize launches + gaps), un-profiled wall clock"}}
         del al
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only, bounded sample)

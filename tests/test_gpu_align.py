@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import GOLDEN, rel_err
 from test_oracle_align import META, NAMES, build
@@ -155,6 +156,28 @@ def test_config2_full_size_vs_oracle(Engine):
     assert all(v < 1e-5 for k, v in margins.items() if k.startswith("grad_")), margins
     assert margins["losses"] < 1e-5 and la[-1] < la[0]
     assert all(v < 1e-4 for k, v in margins.items() if k.startswith("state_")), margins
+
+
+def test_fused_tail_is_bitwise_the_launch_path(Engine, monkeypatch):
+    """A3R_ALIGN_TAIL=fused finishes the iteration inside the main launch (two levels of last-block-done tickets, write-through
+    partial rows, agent-scope acquire) instead of the two finalize launches.  Same sums in the same order: losses and every
+    parameter must come out bit for bit equal, over enough iterations that a stale partial row would show."""
+    edges = [(i, j) for i in range(6) for j in range(6) if i != j]
+    edges, p1, p2, w1, w2, m, init = _scene(edges, 6, 72, 96, 11, False)         # 7 chunks per image, 10 edge sides per image
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(72, 96)] * 6)
+    res = {}
+    for mode in ("launch", "fused"):
+        monkeypatch.setenv("A3R_ALIGN_TAIL", mode)
+        a = Engine(*args)
+        a.set_params(**init)
+        losses = a.run(60, 0.05, "cosine")
+        res[mode] = (losses, {k: host(v).copy() for k, v in a.params.items()}, a.loss_grad())
+    assert np.array_equal(res["launch"][0], res["fused"][0])
+    for k in res["launch"][1]:
+        assert np.array_equal(res["launch"][1][k], res["fused"][1][k]), k
+    assert res["launch"][2][0] == res["fused"][2][0]
+    for k, v in res["launch"][2][1].items():
+        assert torch.equal(v, res["fused"][2][1][k]), k
 
 
 def test_frozen_poses_and_bad_edges(Engine):
