@@ -82,33 +82,31 @@ def flow_read(filename):
 
 
 def rgb(ftensor, true_shape=None):
-    """image_pose.py:93-110."""
+    """Display form of a network image (image_pose.py:93-110): channels last, optionally cut to true_shape = (H, W),
+    uint8 scaled by 1/255 and ImgNorm'ed floats mapped back from [-1, 1], everything clipped to [0, 1].  Lists map elementwise."""
     if isinstance(ftensor, list):
-        return [rgb(x, true_shape=true_shape) for x in ftensor]
-    if isinstance(ftensor, torch.Tensor):
-        ftensor = ftensor.detach().cpu().numpy()
-    if ftensor.ndim == 3 and ftensor.shape[0] == 3:
-        ftensor = ftensor.transpose(1, 2, 0)
-    elif ftensor.ndim == 4 and ftensor.shape[1] == 3:
-        ftensor = ftensor.transpose(0, 2, 3, 1)
+        return [rgb(item, true_shape=true_shape) for item in ftensor]
+    arr = ftensor.detach().cpu().numpy() if isinstance(ftensor, torch.Tensor) else ftensor
+    channels_first = {3: 0, 4: 1}.get(arr.ndim)                 # CHW or BCHW with 3 channels -> HWC / BHWC
+    if channels_first is not None and arr.shape[channels_first] == 3:
+        arr = np.moveaxis(arr, channels_first, -1)
     if true_shape is not None:
-        H, W = true_shape
-        ftensor = ftensor[:H, :W]
-    img = np.float32(ftensor) / 255 if ftensor.dtype == np.uint8 else (ftensor * 0.5) + 0.5
-    return img.clip(min=0, max=1)
+        arr = arr[:true_shape[0], :true_shape[1]]
+    scaled = arr.astype(np.float32) / 255 if arr.dtype == np.uint8 else arr * 0.5 + 0.5
+    return np.clip(scaled, 0, 1)
 
 
 def _resize_pil_image(img, long_edge_size, nearest=False):
-    S = max(img.size)
-    if S > long_edge_size:
-        interp = PIL.Image.LANCZOS if not nearest else PIL.Image.NEAREST
+    """Long edge -> long_edge_size (image_pose.py:112-118): LANCZOS (or NEAREST) when shrinking, BICUBIC when enlarging."""
+    longest = max(img.size)
+    scale = long_edge_size / longest
+    if longest <= long_edge_size:
+        resample = PIL.Image.BICUBIC
     else:
-        interp = PIL.Image.BICUBIC
-    new_size = tuple(int(round(x * long_edge_size / S)) for x in img.size)
-    return img.resize(new_size, interp)
+        resample = PIL.Image.NEAREST if nearest else PIL.Image.LANCZOS
+    return img.resize((int(round(img.size[0] * scale)), int(round(img.size[1] * scale))), resample)
 
 
-# ------------------------------------------------------------------------------------------- cv2.resize restated
 def _lanczos4_weights(frac):
     """8 taps at offsets -3..4 around floor(x): sinc(t) sinc(t/4), normalised to sum 1 (OpenCV interpolateLanczos4)."""
     t = frac[:, None] - np.arange(-3, 5, dtype=np.float64)[None, :]
@@ -162,14 +160,11 @@ def resize_numpy_image(img, long_edge_size):
 
 
 def crop_center(img, crop_width, crop_height):
-    """image_pose.py:149-170 (note the reference's swapped names: cx is the ROW centre)."""
-    h, w = img.shape[:2]
-    cx, cy = h // 2, w // 2
-    x1 = max(cx - crop_height // 2, 0)
-    x2 = min(cx + crop_height // 2, h)
-    y1 = max(cy - crop_width // 2, 0)
-    y2 = min(cy + crop_width // 2, w)
-    return img[x1:x2, y1:y2]
+    """Window of crop_height rows x crop_width columns around the array centre, clipped to the array (image_pose.py:149-170)."""
+    rows, cols = img.shape[:2]
+    r_mid, c_mid = rows // 2, cols // 2
+    r_half, c_half = crop_height // 2, crop_width // 2
+    return img[max(r_mid - r_half, 0):min(r_mid + r_half, rows), max(c_mid - c_half, 0):min(c_mid + c_half, cols)]
 
 
 def crop_img(img, size, pred_depth=None, square_ok=False, nearest=False, crop=True):
@@ -209,18 +204,13 @@ def normalize_pointcloud(point_cloud):
 
 
 def pixel_to_pointcloud(depth_map, focal_length_px):
-    """image_pose.py:206-237: un-project a depth map with a centred pinhole, then min-max normalise -> [H, W, 3] float32."""
-    height, width = depth_map.shape
-    cx = width / 2
-    cy = height / 2
-    u = np.arange(width)
-    v = np.arange(height)
-    u, v = np.meshgrid(u, v)
-    Z = depth_map
-    X = (u - cx) * Z / focal_length_px
-    Y = (v - cy) * Z / focal_length_px
-    point_cloud = np.dstack((X, Y, Z)).astype(np.float32)
-    return normalize_pointcloud(point_cloud)
+    """image_pose.py:206-237: un-project a depth map with a pinhole centred at (W/2, H/2), then min-max normalise -> [H, W, 3] float32.
+    (float64 grid arithmetic exactly as the reference's numpy expression order: the result is pinned bit for bit, prep.npz.)"""
+    rows, cols = depth_map.shape
+    px, py = np.meshgrid(np.arange(cols), np.arange(rows))
+    x_cam = (px - cols / 2) * depth_map / focal_length_px
+    y_cam = (py - rows / 2) * depth_map / focal_length_px
+    return normalize_pointcloud(np.stack((x_cam, y_cam, depth_map), axis=-1).astype(np.float32))
 
 
 _PRIOR_PATH_RULES = {

@@ -1,0 +1,99 @@
+"""GPU: BASELINE config 5's "bf16 MFMA path" (A3R_GEMM=bf16: a0 b0 only = plain bf16 operands, fp32 accumulation) at MODEL SCALE,
+with its own stated tolerances -- it is a reduced-precision mode, never the default, and it is not what bench.py measures.
+
+Two levels, both on ViT-L at 512x384:
+  (1) point maps / confidences of one pair against the numpy oracle (fp32): tensor-max and per-point errors are LOGGED and bounded;
+  (2) pose level: a 6-frame clip (swin-2 window graph, 18 pairs) goes through the fp32-accurate engine and through the bf16 engine,
+      both outputs are aligned by the same PointCloudOptimizer run (same seed, same 200 cosine iterations), and the two camera
+      trajectories are compared with the pose metric of tool/pose_test.py (ATE after Sim(3) alignment, restated in
+      align3r_amd/tool/pose_metrics.py): ATE / trajectory extent is the acceptance number of the mode.
+The frames are synthetic noise and the weights synthetic, so the trajectory has no physical meaning; what is measured is how far
+the reduced precision moves the aligner's answer on the same problem."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_view_arrays, pair_margins, record_margin, rel_err
+from align3r_amd.weights import VITL, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+H, W = 384, 512
+
+# stated tolerances of the mode (measured margins are in the [parity-margin] log lines / DESIGN.md section 2)
+# measured on MI355X (round 2): tensor-max 2.9e-2 / 2.1e-2 / 1.4e-2 / 1.7e-2 (pts3d, conf, pts3d_in_other_view, conf); per point
+# median 2.2 %, 99th percentile 10.5 % on pts3d (near-origin points), 3 % on pts3d_in_other_view; ATE / extent 3.1e-3, largest
+# camera rotation difference 3.0 degrees, final alignment losses equal to three digits.
+BF16_TENSOR_MAX = 5e-2          # max|a - b| / max|b| of a point map or confidence map
+BF16_POINT_P99 = 2e-1           # 99 % of the points within 20 % of their own norm
+BF16_ATE_REL = 1e-2             # ATE <= 1 % of the rms trajectory extent after aligning the two runs' trajectories
+BF16_ROT_DEG = 6.0              # largest difference of a camera orientation
+
+
+def to_dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+@pytest.fixture(scope="module")
+def engines():
+    import os
+    from align3r_amd.engine import PairEngine
+    sd = synthetic_state_dict(VITL, 0)
+    old = os.environ.get("A3R_GEMM")
+    os.environ["A3R_GEMM"] = "bf16"
+    try:
+        e16 = PairEngine(VITL, sd)
+    finally:
+        if old is None:
+            os.environ.pop("A3R_GEMM", None)
+        else:
+            os.environ["A3R_GEMM"] = old
+    e32 = PairEngine(VITL, sd)
+    return e32, e16
+
+
+def test_bf16_mode_pair_vs_oracle(engines):
+    from oracle import model_np as O
+    e32, e16 = engines
+    v = make_view_arrays(2, H, W, seed=2)
+    r = e16.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
+    ref = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
+    m = pair_margins("bf16_mode_vitl_512x384_vs_oracle", {k: t.cpu().numpy() for k, t in r.items()}, ref)
+    for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
+        assert m[f"{k}/tensor_max"] < BF16_TENSOR_MAX, (k, m[f"{k}/tensor_max"])
+        assert m[f"{k}/tensor_max"] > 1e-4, "bf16 mode must really be a different arithmetic"
+        assert m[f"{k}/per_elem(max,p99.9,p99,p50)"][2] < BF16_POINT_P99, (k, m[f"{k}/per_elem(max,p99.9,p99,p50)"])
+
+
+def test_bf16_mode_pose_level(engines):
+    import align3r_amd
+    align3r_amd.install_as_dust3r()
+    from dust3r.cloud_opt import global_aligner
+    from dust3r.image_pairs import make_pairs
+    from align3r_amd.tool.pose_metrics import align_trajectory, ate_rmse
+    e32, e16 = engines
+    n = 6
+    v = make_view_arrays(n, H, W, seed=8)
+    pairs = make_pairs([dict(idx=i) for i in range(n)], "swin-2-noncyclic", symmetrize=True)
+    edges = [(a["idx"], b["idx"]) for a, b in pairs]
+    cat = lambda side, k: np.concatenate([v[e[side]][k] for e in edges])
+    ins = to_dev(cat(0, 0), cat(1, 0), cat(0, 1), cat(1, 1))
+    poses = {}
+    for name, eng in (("f32", e32), ("bf16", e16)):
+        r = eng.forward(*ins)
+        out = dict(view1=dict(idx=[i for i, _ in edges]), view2=dict(idx=[j for _, j in edges]),
+                   pred1=dict(pts3d=r["pts3d_1"], conf=r["conf_1"]), pred2=dict(pts3d_in_other_view=r["pts3d_2"], conf=r["conf_2"]))
+        torch.manual_seed(3)
+        scene = global_aligner(out, False, [], "cuda", verbose=False, min_conf_thr=3)
+        loss = scene.compute_global_alignment(init=None, niter=200, schedule="cosine", lr=0.05)
+        poses[name] = (scene.get_im_poses().cpu().numpy().astype(np.float64), loss, {k: t.cpu().numpy() for k, t in r.items()})
+    P32, P16 = poses["f32"][0], poses["bf16"][0]
+    est, _ = align_trajectory(P16, P32, correct_scale=True)
+    ate = ate_rmse(P32, est)
+    c = P32[:, :3, 3]
+    extent = float(np.sqrt(((c - c.mean(0)) ** 2).sum(1).mean()))
+    rot = [np.degrees(np.arccos(np.clip((np.trace(P32[i, :3, :3].T @ est[i, :3, :3]) - 1) / 2, -1, 1))) for i in range(n)]
+    record_margin("bf16_mode_pose_level", ate=ate, extent=extent, ate_over_extent=ate / extent, max_rot_deg=max(rot),
+                  loss_f32=poses["f32"][1], loss_bf16=poses["bf16"][1],
+                  pts3d_1_tensor_max=rel_err(poses["bf16"][2]["pts3d_1"], poses["f32"][2]["pts3d_1"]))
+    assert ate / extent < BF16_ATE_REL, (ate, extent)
+    assert max(rot) < BF16_ROT_DEG, rot

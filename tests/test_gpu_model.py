@@ -211,3 +211,43 @@ def test_reduced_precision_modes_state_their_tolerance(monkeypatch, mode, tol):
         assert max(errs.values()) > 1e-4            # it really is a different arithmetic
     from align3r_amd import ops
     assert ops.bf3_set_products(6) == 6             # the handle's mode does not leak out of its forward
+
+
+@pytest.mark.parametrize("H,W,B", [(48, 80, 1), (64, 96, 2), (48, 80, 3)])
+def test_forward_stays_inside_its_buffers(tiny_engine, H, W, B):
+    """Guard derived from the one GPU fault in this repository's records (gpurun_out/dbg2.log of round 1, 04:05, before the first
+    HIP commit: 'Write access to a read-only page' inside the DPT head's last 3x3 conv, 128 -> 128 channels at full resolution, on
+    the TINY 64x96 forward).  The forward runs on a workspace of EXACTLY a3r_model_workspace_bytes and on
+    output tensors cut out of one allocation, each followed by a canary region; every canary must be untouched afterwards.
+    48x80 gives 15 tokens per image: ragged (FULL = false) GEMM / conv tiles, odd row counts for B = 1 and 3."""
+    v = make_view_arrays(3, H, W, seed=6)
+    idx = [(0, 1), (2, 1), (1, 2)][:B]
+    ins = to_dev(*[np.concatenate([v[i if s == 0 else j][k] for i, j in idx]) for k in (0, 1) for s in (0, 1)])
+    img1, img2, pd1, pd2 = ins[0], ins[1], ins[2], ins[3]
+    need = tiny_engine.workspace_bytes(B, H, W)
+    PAD = 1 << 16                                                   # 64 KB of canary after every region
+    P = H * W
+    sizes = [need, B * P * 3 * 4, B * P * 4, B * P * 3 * 4, B * P * 4]
+    offs, total = [], PAD
+    for s in sizes:
+        offs.append(total)
+        total += (s + 255) // 256 * 256 + PAD
+    arena = torch.full((total,), 0xA5, dtype=torch.uint8, device="cuda")
+    view = lambda o, n: arena[o:o + n]
+    saved = tiny_engine.workspace
+    try:
+        tiny_engine.workspace = view(offs[0], need)
+        out = dict(pts3d_1=view(offs[1], sizes[1]).view(torch.float32).view(B, H, W, 3), conf_1=view(offs[2], sizes[2]).view(torch.float32).view(B, H, W),
+                   pts3d_2=view(offs[3], sizes[3]).view(torch.float32).view(B, H, W, 3), conf_2=view(offs[4], sizes[4]).view(torch.float32).view(B, H, W))
+        tiny_engine.forward(img1, img2, pd1, pd2, out=out)
+        torch.cuda.synchronize()
+        assert tiny_engine.workspace.data_ptr() == arena.data_ptr() + offs[0]          # the engine did not re-allocate
+    finally:
+        tiny_engine.workspace = saved
+    used = torch.zeros(total, dtype=torch.bool, device="cuda")
+    for o, s in zip(offs, sizes):
+        used[o:o + s] = True
+    assert bool((arena[~used] == 0xA5).all()), "the forward wrote outside its workspace / output buffers"
+    ref = tiny_engine.forward(img1, img2, pd1, pd2)                                    # same results on ordinary buffers
+    for k in out:
+        assert torch.equal(out[k], ref[k]), k

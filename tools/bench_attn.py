@@ -9,7 +9,10 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for B, H, N in [(84, 16, 768), (84, 12, 768), (24, 16, 768)]:
+SHAPES = [(84, 16, 768), (84, 12, 768), (24, 16, 768)]
+if os.environ.get("A3R_ATTN_ONE"):
+    SHAPES = SHAPES[:1]
+for B, H, N in SHAPES:
     D = H * 64
     qkv3 = ops.split_bf3(torch.randn(B * N, 3 * D, device="cuda"))
     us = timeit(lambda: ops.attention_bf3(qkv3, qkv3, qkv3, B, H, N, N, q_col=0, k_col=D, v_col=2 * D))
