@@ -4,6 +4,7 @@
 #include "common.h"
 #include "bf3.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace a3r {
 
@@ -45,6 +46,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                          __builtin_fmaf(t.w, wv.w, bv.w)};
         if (BF3) bf3_store4(y3, (lane + 64 * i) * 4, o, pair);
         else yr[lane + 64 * i] = o;
+    }
+}
+
+// Row-PAIR bf3 output (the layout every transformer GEMM input uses, bf3.h): ONE WAVE NORMALISES TWO ROWS (2j, 2j + 1) and
+// stores their interleaved image -- 12 D contiguous bytes -- through LDS as whole 1 KB wave stores.  The one-row form above writes
+// a row's planes as 8-byte pieces, 16 of every 48 bytes per instruction (a lane owns 4 consecutive k = half of each plane's
+// 16-byte unit), and in the pair layout a single row is 192-byte runs at a 384-byte stride; here every store instruction covers
+// eight whole cache lines, and the two rows' loads and reductions are in flight together.  Same arithmetic, same rounding.
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_pair_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, char* __restrict__ y3, int M, int D, float eps) {
+#pragma clang fp contract(off)
+    // per wave two 3 KB images: the pair's 256 k of one step i (8 k-blocks x 384 B, contiguous in the pair layout), double-buffered
+    __shared__ __attribute__((aligned(16))) char img_all[4][2][3072];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + wave) * 2;
+    if (r0 >= M) return;                                                        // wave-uniform; M is even in this layout's callers
+    const bool two = r0 + 1 < M;
+    const f32x4* x0 = reinterpret_cast<const f32x4*>(x + (size_t)r0 * D);
+    const f32x4* x1 = reinterpret_cast<const f32x4*>(x + (size_t)(two ? r0 + 1 : r0) * D);
+    f32x4 v0[VPL], v1[VPL];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        v0[i] = x0[lane + 64 * i];
+        v1[i] = x1[lane + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        s0 += v0[i].x + v0[i].y + v0[i].z + v0[i].w;
+        s1 += v1[i].x + v1[i].y + v1[i].z + v1[i].w;
+    }
+    const float mean0 = wave_sum(s0) / (float)D, mean1 = wave_sum(s1) / (float)D;
+    float ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        v0[i] = v0[i] - mean0;
+        v1[i] = v1[i] - mean1;
+        ss0 += v0[i].x * v0[i].x + v0[i].y * v0[i].y + v0[i].z * v0[i].z + v0[i].w * v0[i].w;
+        ss1 += v1[i].x * v1[i].x + v1[i].y * v1[i].y + v1[i].z * v1[i].z + v1[i].w * v1[i].w;
+    }
+    const float rstd0 = 1.f / sqrtf(wave_sum(ss0) / (float)D + eps), rstd1 = 1.f / sqrtf(wave_sum(ss1) / (float)D + eps);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w);
+    const f32x4* br = reinterpret_cast<const f32x4*>(b);
+    char* dst = y3 + (size_t)(r0 >> 1) * ((size_t)12 * D);
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        char* img = img_all[wave][i & 1];
+        const f32x4 wv = wr[lane + 64 * i], bv = br[lane + 64 * i];
+        const f32x4 t0 = v0[i] * rstd0, t1 = v1[i] * rstd1;
+        const f32x4 o0 = {__builtin_fmaf(t0.x, wv.x, bv.x), __builtin_fmaf(t0.y, wv.y, bv.y), __builtin_fmaf(t0.z, wv.z, bv.z),
+                          __builtin_fmaf(t0.w, wv.w, bv.w)};
+        const f32x4 o1 = {__builtin_fmaf(t1.x, wv.x, bv.x), __builtin_fmaf(t1.y, wv.y, bv.y), __builtin_fmaf(t1.z, wv.z, bv.z),
+                          __builtin_fmaf(t1.w, wv.w, bv.w)};
+        bf3_store4(img, lane * 4, o0, 1);                                      // row parity 0: offset 0 of every 384-byte k block
+        bf3_store4(img + 192, lane * 4, o1, 1);                                // row parity 1: + 192
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): the image is wave-private
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int un = u * 64 + lane;
+            const u32x4 dv = *reinterpret_cast<const u32x4*>(img + un * 16);
+            if (two || ((un * 16) % 384) < 192) *reinterpret_cast<u32x4*>(dst + (size_t)i * 3072 + (size_t)un * 16) = dv;
+        }
     }
 }
 
@@ -277,6 +342,16 @@ static int launch_layernorm(const float* x, const float* w, const float* b, floa
     hipStream_t st = as_stream(stream);
     ProfScope prof(PK_LAYERNORM, (BF3 ? 10.0 : 8.0) * M * D, st);
     dim3 grid((M + 3) / 4), block(256);
+    static const bool one_row = getenv("A3R_LN_ONE_ROW") != nullptr;           // developer A/B switch
+    if (BF3 && pair && !one_row && (D == 1024 || D == 768 || D == 256)) {
+        const dim3 g2((M + 7) / 8);
+        char* y3 = reinterpret_cast<char*>(y);
+        if (D == 1024) hipLaunchKernelGGL(layernorm_pair_kernel<4>, g2, block, 0, st, x, w, b, y3, M, D, eps);
+        else if (D == 768) hipLaunchKernelGGL(layernorm_pair_kernel<3>, g2, block, 0, st, x, w, b, y3, M, D, eps);
+        else hipLaunchKernelGGL(layernorm_pair_kernel<1>, g2, block, 0, st, x, w, b, y3, M, D, eps);
+        A3R_LAUNCH_CHECK();
+        return A3R_OK;
+    }
     if (D == 1024) hipLaunchKernelGGL((layernorm_kernel<4, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps, pair);
     else if (D == 768) hipLaunchKernelGGL((layernorm_kernel<3, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps, pair);
     else if (D == 256) hipLaunchKernelGGL((layernorm_kernel<1, BF3>), grid, block, 0, st, x, w, b, y, M, D, eps, pair);
