@@ -20,11 +20,16 @@ class Epilogue(C.Structure):
     _fields_ = [("epi", C.c_int), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("relu_a", C.c_int),
                 ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
-                ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int)]
+                ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int),
+                ("out_fh2", C.c_int)]
 
 
 class GroupPtrs(C.Structure):
     _fields_ = [("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("resid", c_void), ("resid2", c_void)]
+
+
+class GroupPtrsFh2(C.Structure):
+    _fields_ = [("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("w_scale", C.c_float)]
 
 
 class ModelConfigC(C.Structure):
@@ -72,6 +77,14 @@ SIGNATURES = {
     "a3r_linear_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_umeyama_chunks": (C.c_int, [C.c_int]),
     "a3r_umeyama_moments": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
+    "a3r_fh2_bytes": (C.c_size_t, [C.c_long, C.c_int]),
+    "a3r_split_fh2": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, C.c_float, c_void]),
+    "a3r_absmax": (C.c_int, [c_void, C.c_long, c_void, c_void]),
+    "a3r_fh2_weight_scale": (C.c_float, [C.c_float]),
+    "a3r_layernorm_fh2": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
+    "a3r_linear_fh2_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
+    "a3r_linear_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
+    "a3r_attention_bf3_fh2out": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_bf3_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "a3r_bf3_set_products": (C.c_int, [C.c_int]),
     "a3r_split_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),

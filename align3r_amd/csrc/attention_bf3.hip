@@ -17,6 +17,7 @@
 // LDS images are conflict-free for ds_read_b128 by padding: K rows are 24 + 1 units, V^T rows 8 + 1 units (odd strides).
 #include "common.h"
 #include "bf3.h"
+#include "fh2.h"
 
 namespace a3r {
 
@@ -42,6 +43,7 @@ struct Attn3Args {
     size_t pq, pk, pv, po;                  // row pitches in bytes (6 x leading dimension)
     int B, H, Nq, Nk;
     int ldo, out_pair;                      // o: leading dimension in elements; row-pair layout (bf3.h) for a GEMM-only consumer
+    int out_fh2;                            // o in fh2 form (fh2.h, scale 1, plain rows) for an a3r_linear_fh2 output projection
 };
 
 typedef const __attribute__((address_space(1))) void* a3_gptr;
@@ -237,14 +239,16 @@ __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(At
     const float inv_l = 1.f / l_tot;
     if (q_row < a.Nq) {
         // lane (query, half) holds d = 32 db + 8 g + 4 half + (0..3): half a bf3 unit per plane
-        char* op = a.o + bf3_row_offset((long)b * a.Nq + q_row, a.ldo, a.out_pair);
+        char* op = a.out_fh2 ? a.o + ((size_t)b * a.Nq + q_row) * fh2_row_bytes(a.ldo)
+                             : a.o + bf3_row_offset((long)b * a.Nq + q_row, a.ldo, a.out_pair);
 #pragma unroll
         for (int db = 0; db < 2; db++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const f32x4 v = {oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l, oacc[db][4 * g + 2] * inv_l,
                                  oacc[db][4 * g + 3] * inv_l};
-                bf3_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v, a.out_pair);
+                if (a.out_fh2) fh2_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v);
+                else bf3_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v, a.out_pair);
             }
     }
 }
@@ -252,8 +256,8 @@ __global__ __launch_bounds__(A3T, A3_WAVES == 4 ? 2 : 1) void attn_bf3_kernel(At
 }  // namespace a3r
 using namespace a3r;
 
-extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
-                                 int B, int H, int Nq, int Nk, int out_pair, void* stream) {
+static int attention_bf3_impl(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
+                              int B, int H, int Nq, int Nk, int out_pair, int out_fh2, void* stream) {
     A3R_CHECK_ARG(q3 && k3 && v3 && o3, "a3r_attention_bf3: null pointer");
     A3R_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "a3r_attention_bf3: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     A3R_CHECK_ARG(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ldo >= H * 64, "a3r_attention_bf3: row strides < H*64");
@@ -268,7 +272,7 @@ extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ld
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
     }
     Attn3Args a = {static_cast<const char*>(q3), static_cast<const char*>(k3), static_cast<const char*>(v3), static_cast<char*>(o3),
-                   (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk, ldo, out_pair ? 1 : 0};
+                   (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk, ldo, out_pair ? 1 : 0, out_fh2 ? 1 : 0};
     const int nqb = (Nq + A3Q - 1) / A3Q, groups = B * H;
     dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION_BF3, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
@@ -278,4 +282,14 @@ extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ld
     else hipLaunchKernelGGL(attn_bf3_kernel<1>, grid, dim3(A3T), A3_LDS_BYTES, as_stream(stream), a);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
+}
+
+extern "C" int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
+                                 int B, int H, int Nq, int Nk, int out_pair, void* stream) {
+    return attention_bf3_impl(q3, ldq, k3, ldk, v3, ldv, o3, ldo, B, H, Nq, Nk, out_pair, 0, stream);
+}
+
+extern "C" int a3r_attention_bf3_fh2out(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o2, int ldo,
+                                        int B, int H, int Nq, int Nk, void* stream) {
+    return attention_bf3_impl(q3, ldq, k3, ldk, v3, ldv, o2, ldo, B, H, Nq, Nk, 0, 1, stream);
 }

@@ -3,6 +3,7 @@
 // layout allows, one wave per row for the row reductions (64-wide DPP/shuffle sums).
 #include "common.h"
 #include "bf3.h"
+#include "fh2.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -110,6 +111,71 @@ __global__ __launch_bounds__(256) void layernorm_pair_kernel(const float* __rest
             const u32x4 dv = *reinterpret_cast<const u32x4*>(img + un * 16);
             if (two || ((un * 16) % 384) < 192) *reinterpret_cast<u32x4*>(dst + (size_t)i * 3072 + (size_t)un * 16) = dv;
         }
+    }
+}
+
+// fh2 output (fh2.h; scale 1): one wave per row, a lane owns 8 CONSECUTIVE k per step (two adjacent float4 loads), so it writes the
+// two planes' 16-byte units of its group -- 32 contiguous bytes per lane, 2 KB contiguous per wave and step.
+template <int VPL>   // 8-k groups per lane: D = 512 * VPL ... handled as D = 64 * 8 * VPL; D = 1024 -> 2, 768 -> 1.5 (generic path)
+__global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps) {
+#pragma clang fp contract(off)
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    f32x4 v[VPL][2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        v[i][0] = xr[2 * (lane + 64 * i)];
+        v[i][1] = xr[2 * (lane + 64 * i) + 1];
+        s += (v[i][0].x + v[i][0].y + v[i][0].z + v[i][0].w) + (v[i][1].x + v[i][1].y + v[i][1].z + v[i][1].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            v[i][h] = v[i][h] - mean;
+            ss += v[i][h].x * v[i][h].x + v[i][h].y * v[i][h].y + v[i][h].z * v[i][h].z + v[i][h].w * v[i][h].w;
+        }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w);
+    const f32x4* br = reinterpret_cast<const f32x4*>(b);
+    char* yr = y2 + (size_t)row * fh2_row_bytes(D);
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        f32x4 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c = 2 * (lane + 64 * i) + h;
+            const f32x4 t = v[i][h] * rstd, wv = wr[c], bv = br[c];
+            o[h] = f32x4{__builtin_fmaf(t.x, wv.x, bv.x), __builtin_fmaf(t.y, wv.y, bv.y), __builtin_fmaf(t.z, wv.z, bv.z),
+                         __builtin_fmaf(t.w, wv.w, bv.w)};
+        }
+        fh2_store8(yr, (lane + 64 * i) * 8, o[0], o[1]);
+    }
+}
+// any D % 32 == 0: lanes stride over the row's 8-k groups (three passes over an L1/L2-resident row)
+__global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps) {
+#pragma clang fp contract(off)
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) { const float c = xr[i] - mean; ss += c * c; }
+    const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
+    char* yr = y2 + (size_t)row * fh2_row_bytes(D);
+    for (int k0 = lane * 8; k0 < D; k0 += 512) {
+        f32x4 o[2];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j >> 2][j & 3] = __builtin_fmaf((xr[k0 + j] - mean) * rstd, w[k0 + j], b[k0 + j]);
+        fh2_store8(yr, k0, o[0], o[1]);
     }
 }
 
@@ -365,6 +431,21 @@ extern "C" int a3r_layernorm(const float* x, const float* w, const float* b, flo
     A3R_CHECK_ARG(x && w && b && y, "a3r_layernorm: null pointer");
     A3R_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0, "a3r_layernorm: bad shape M=%d D=%d", M, D);
     return launch_layernorm<false>(x, w, b, y, M, D, eps, stream);
+}
+
+extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b, void* y2, int M, int D, float eps, void* stream) {
+    A3R_CHECK_ARG(x && w && b && y2, "a3r_layernorm_fh2: null pointer");
+    A3R_CHECK_ARG(M > 0 && D > 0 && D % 32 == 0, "a3r_layernorm_fh2: bad shape M=%d D=%d (D must be a multiple of 32)", M, D);
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(y2) & 15) == 0, "a3r_layernorm_fh2: y2 must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PK_LAYERNORM, 8.0 * M * D, st);
+    dim3 grid((M + 3) / 4), block(256);
+    char* y = static_cast<char*>(y2);
+    if (D == 1024) hipLaunchKernelGGL(layernorm_fh2_kernel<2>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (D == 512) hipLaunchKernelGGL(layernorm_fh2_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_fh2_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
 }
 
 extern "C" int a3r_layernorm_bf3(const float* x, const float* w, const float* b, void* y3, int M, int D, float eps, int pair,

@@ -1,0 +1,61 @@
+// "fh2": an fp32 matrix held as TWO fp16 planes, x ~ (h0 + h1) / s with h0 = rn_f16(s x), h1 = rn_f16(s x - h0) and s a power of
+// two chosen per matrix (1 for activations, 2^k putting max|w| into [2^12, 2^13) for weights).  h0 + h1 carries 22 significant bits of
+// s x (fp32 has 24) whenever |s x| >= 2^-3 -- below that h1 is an fp16 subnormal and the ABSOLUTE error is bounded by 2^-25 / s.
+// An fp32 GEMM is then evaluated on the fp16 matrix cores as
+//     a b ~ h0 g0 + (h0 g1 + h1 g0)          [dropped: h1 g1 <= 2^-22 |a b|]
+// THREE v_mfma_f32_16x16x32_f16 passes per k-step, every fp16 x fp16 product exact in the fp32 accumulator.  The operand error
+// (2^-22 relative, random sign) is averaged over the K terms of a dot product and sits well below the fp32 accumulation error that
+// the reference's own fp32 GEMM has: measured against float64 the result is as accurate as the exact-fp32 MFMA kernel's
+// (tests/test_gpu_fh2.py: max |err| / sum|a||b| within 1.2x of a3r_linear's), at half the matrix passes and two thirds of the
+// operand bytes of the exact three-plane bf16 form (bf3.h), which stays available (A3R_GEMM=bf3).
+// Memory layout of a [R, K] matrix (K % 32 == 0): [R][K/8][2][8] fp16 -- per row and group of 8 consecutive k the two planes'
+// 16-byte pieces are adjacent (32 bytes); row pitch 4 K bytes; the 32 k of one GEMM stage are exactly one 128-byte line.
+#pragma once
+#include "common.h"
+
+namespace a3r {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float fh2_f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t fh2_u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t fh2_row_bytes(int K) { return (size_t)K * 4; }
+
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {       // v_cvt_pkrtz is round-to-zero: use the rn conversions
+    fh2_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2v));
+}
+__device__ __forceinline__ float f16lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2v, p)[0]; }
+__device__ __forceinline__ float f16hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2v, p)[1]; }
+
+// two (already scaled) floats -> two packed fp16 pairs (low half = a, high half = b)
+__device__ __forceinline__ void fh2_split2(float a, float b, uint32_t& p0, uint32_t& p1) {
+    p0 = pk_f16(a, b);
+    p1 = pk_f16(a - f16lo(p0), b - f16hi(p0));
+}
+
+// eight consecutive k (k0 % 8 == 0) of one fh2 row: 32 contiguous bytes
+__device__ __forceinline__ void fh2_store8(char* row, int k0, f32x4 lo, f32x4 hi) {
+    uint32_t a0, a1, b0, b1, c0, c1, d0, d1;
+    fh2_split2(lo.x, lo.y, a0, a1);
+    fh2_split2(lo.z, lo.w, b0, b1);
+    fh2_split2(hi.x, hi.y, c0, c1);
+    fh2_split2(hi.z, hi.w, d0, d1);
+    char* d = row + (k0 >> 3) * 32;
+    *reinterpret_cast<fh2_u32x4*>(d) = fh2_u32x4{a0, b0, c0, d0};
+    *reinterpret_cast<fh2_u32x4*>(d + 16) = fh2_u32x4{a1, b1, c1, d1};
+}
+
+// four consecutive k (k0 % 4 == 0): half of each plane's 16-byte unit
+__device__ __forceinline__ void fh2_store4(char* row, int k0, f32x4 v) {
+    uint32_t a0, a1, b0, b1;
+    fh2_split2(v.x, v.y, a0, a1);
+    fh2_split2(v.z, v.w, b0, b1);
+    char* d = row + (k0 >> 3) * 32 + ((k0 >> 2) & 1) * 8;
+    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2_*>(d) = u32x2_{a0, b0};
+    *reinterpret_cast<u32x2_*>(d + 16) = u32x2_{a1, b1};
+}
+
+}  // namespace a3r

@@ -1,0 +1,360 @@
+// fp32 nn.Linear on the fp16 matrix cores of gfx950 ("fh2" GEMM): y = x W^T from two-plane fp16 splits of both operands (fh2.h),
+// three v_mfma_f32_16x16x32_f16 passes per 32-deep k-step -- h0 g0 + h0 g1 + h1 g0, every fp16 x fp16 product exact in the fp32
+// accumulator, 22-bit operands: as accurate against float64 as the exact-fp32 MFMA GEMM (tests/test_gpu_fh2.py), at HALF the matrix
+// passes and two thirds of the operand bytes of the three-plane bf16 form (gemm_bf3.hip).  Serves the transformer call sites of
+// a3r_linear (croco/models/blocks.py:58-169 qkv / proj / fc1 / fc2 / projq / projk / projv, patch embeddings, decoder_embed,
+// zero-convs); the DPT convolutions and the attention products stay on the bf3 kernels.
+//
+// Structure (64-wide waves), as gemm_bf3.hip: a workgroup computes a BM x BN tile with WM x WN waves of 16x16 accumulator tiles;
+// K is walked in 32-deep stages copied global -> LDS by LDS-DMA (global_load_lds_dwordx4), NS stages deep, one raw s_barrier per
+// stage with a counted s_waitcnt vmcnt.  A stage's LDS image is [rows][8 units] (128 bytes = one cache line per row); ds_read_b128
+// conflicts are removed by an XOR swizzle of the unit index applied on the DMA's SOURCE side (the LDS image is lane-linear):
+// physical unit j of row r holds logical unit j ^ swz(r), swz(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 2), conflict-free for the
+// 16x16x32 operand pattern (rows = lane & 15, k-group = lane >> 4) under the documented ds_read_b128 lane groups.
+// Epilogues: the accumulator is multiplied by the exact power of two that undoes the weight scale, then handed to the epilogues of
+// gemm_common.h (bias, GELU, residuals, RoPE, fp32 / bf3 outputs); out_fh2 writes the two-plane fp16 form for the next GEMM.
+#include "gemm_common.h"
+#include "fh2.h"
+#include <cstdlib>
+
+namespace a3r {
+
+typedef const __attribute__((address_space(1))) void* fh2_gptr;
+typedef __attribute__((address_space(3))) void* fh2_lptr;
+
+template <int N> __device__ __forceinline__ void fh2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void fh2_wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: fh2_wait_vmcnt<0>(); break;   case 1: fh2_wait_vmcnt<1>(); break;   case 2: fh2_wait_vmcnt<2>(); break;
+        case 3: fh2_wait_vmcnt<3>(); break;   case 4: fh2_wait_vmcnt<4>(); break;   case 5: fh2_wait_vmcnt<5>(); break;
+        case 6: fh2_wait_vmcnt<6>(); break;   case 8: fh2_wait_vmcnt<8>(); break;   case 9: fh2_wait_vmcnt<9>(); break;
+        case 12: fh2_wait_vmcnt<12>(); break;
+        default: fh2_wait_vmcnt<0>(); break;                                // always safe
+    }
+}
+
+struct Fh2Args {
+    GemmArgs g;
+    float inv_wscale[4];      // per group: 1 / (power-of-two scale the weights were stored with)
+};
+
+__device__ __forceinline__ int fh2_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
+
+// ---- out_fh2 epilogue: bias / GELU / ReLU in the accumulator layout, the two fp16 planes go to a wave-private LDS image shaped like
+// the final memory (32 rows x 128 bytes per 32-column block), and come back one 16-byte unit per lane: every store instruction
+// writes whole 128-byte lines.  lds: EPI_FH2_WAVE_BYTES per wave.
+constexpr int EPI_FH2_PITCH = 144;                       // bytes per image row (128 + 16: rows rotate over the banks)
+constexpr int EPI_FH2_WAVE_BYTES = 32 * EPI_FH2_PITCH;   // 4608
+template <int TM, bool FULL>
+__device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int n0, int wrow0,
+                                                 int wcol0, int lane, char* img) {
+    static_assert(TM % 2 == 0, "halves of 32 rows");
+    const a3r_epilogue& ep = g.epi;
+    const int quad = lane >> 4, lcol = lane & 15;
+    char* out = reinterpret_cast<char*>(P.C);
+    const size_t pitch = fh2_row_bytes(g.N);
+    const int kcol0 = n0 + wcol0;                            // a multiple of 32: one whole 128-byte k block of the output rows
+#pragma unroll
+    for (int half = 0; half < TM / 2; half++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = n0 + wcol0 + j * 16 + lcol;
+            const bool col_ok = FULL || col < g.N;
+            const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
+            const int cw = j * 16 + lcol;
+            char* dcol = img + (cw >> 3) * 32 + (cw & 7) * 2;
+#pragma unroll
+            for (int il = 0; il < 2; il++)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int i = half * 2 + il;
+                    float v0 = acc[i][j][e] + bias, v1 = acc[i][j][e + 1] + bias;
+                    if (ep.epi == A3R_EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
+                    else if (ep.epi == A3R_EPI_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    uint32_t p0, p1;
+                    fh2_split2(v0, v1, p0, p1);                  // low half: row e, high half: row e + 1
+                    char* d = dcol + (il * 16 + quad * 4 + e) * EPI_FH2_PITCH;
+                    *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
+                    *reinterpret_cast<uint16_t*>(d + 16) = (uint16_t)p1;
+                    *reinterpret_cast<uint16_t*>(d + EPI_FH2_PITCH) = (uint16_t)(p0 >> 16);
+                    *reinterpret_cast<uint16_t*>(d + EPI_FH2_PITCH + 16) = (uint16_t)(p1 >> 16);
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; it++) {                          // 32 rows x 8 units = 4 x 64 lanes
+            const int u = it * 64 + lane, r = u >> 3, un = u & 7;
+            const int grow = m0 + wrow0 + half * 32 + r;
+            const fh2_u32x4 dv = *reinterpret_cast<const fh2_u32x4*>(img + r * EPI_FH2_PITCH + un * 16);
+            if (FULL || (grow < g.M && kcol0 + (un >> 1) * 8 < g.N))
+                *reinterpret_cast<fh2_u32x4*>(out + (size_t)grow * pitch + (size_t)(kcol0 >> 3) * 32 + un * 16) = dv;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // the reads are done before the next half overwrites the image
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool FULL>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_fh2_kernel(Fh2Args fa) {
+    const GemmArgs& g = fa.g;
+    constexpr int NT = WM * WN * 64, U = 8;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int SA = BM * U, SB = BN * U;                                 // 16-byte units per stage
+    static_assert(SA % NT == 0 && SB % NT == 0, "whole DMA rounds");
+    constexpr int LA = SA / NT, LB = SB / NT, LPS = LA + LB;               // DMAs per thread per stage
+    static_assert(WTN == 32 && WTM % 32 == 0, "wave tiles are 32 columns wide (epilogues) and multiples of 32 rows");
+    constexpr int STAGE = (SA + SB) * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // XCD-aware bijective remap (blocks b and b+8 share an XCD), then group / tile decomposition
+    const int nwg = g.tiles_per_group * g.groups;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r8 = nwg & 7;
+    int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int grp = wgid / g.tiles_per_group;
+    wgid -= grp * g.tiles_per_group;
+    const GroupPtrs& P = g.grp[grp];
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid - tile_m * g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const size_t pitch = fh2_row_bytes(g.K);
+    const char* srcA[LA];
+    const char* srcB[LB];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
+        const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
+        srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + (j ^ fh2_swz(r)) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; i++) {
+        const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
+        const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
+        srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + (j ^ fh2_swz(r)) * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
+        const size_t koff = (size_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < LA; i++) __builtin_amdgcn_global_load_lds((fh2_gptr)(srcA[i] + koff), (fh2_lptr)(base + NT * 16 * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LB; i++)
+            __builtin_amdgcn_global_load_lds((fh2_gptr)(srcB[i] + koff), (fh2_lptr)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+    };
+    const int nk = g.K / 32;
+    auto acquire = [&](int kt) {
+        const int rem = nk - 1 - kt, fly = rem < NS - 2 ? rem : NS - 2;
+        fh2_wait_vmcnt_dyn(fly * LPS);
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+    };
+    for (int t = 0; t < NS - 1 && t < nk; t++) issue(t, t);
+
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
+    // lane (row = lane & 15, k-group = lane >> 4) reads, per plane p, physical unit (2 kg + p) ^ swz(row) of its row
+    const int frow = lane & 15, kg = lane >> 4, sw = fh2_swz(frow);
+    int offA[2], offB[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = (2 * kg + p) ^ sw;
+        offA[p] = ((wm * WTM + frow) * U + c) * 16;
+        offB[p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
+    }
+    for (int kt = 0; kt < nk; kt++) {
+        acquire(kt);
+        const char* sb = smem + (kt % NS) * STAGE;
+        f16x8 af[TM][2], bf[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(sb + offA[p] + i * 16 * U * 16);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) bf[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    }
+    // undo the weight scale (an exact power of two), then the shared epilogues
+    const float inv = fa.inv_wscale[grp];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = acc[i][j] * inv;
+    static_assert(NS * STAGE >= WM * WN * epi_lds_wave_bytes(WTM), "the LDS epilogue image fits in the stage ring");
+    if (g.epi.out_fh2) {                                       // wave-uniform
+        __syncthreads();                                       // every wave is done reading the last stage
+        fh2_epilogue_out<TM, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane, smem + wave * EPI_FH2_WAVE_BYTES);
+    } else if (epilogue16_lds_ok(g, P)) {
+        __syncthreads();
+        gemm_epilogue16_lds<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane,
+                                          reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)));
+    } else {
+        gemm_epilogue16<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
+    }
+}
+
+// fp32 [M, ldx] -> fh2 [M][K/8][2][8]: one thread per group of 8 consecutive k (32 B in, 32 contiguous bytes out)
+__global__ __launch_bounds__(256) void split_fh2_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8, float scale) {
+    const long total = M * K8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / K8;
+        const int kg = (int)(i - row * K8);
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + row * ldx + kg * 8);
+        fh2_store8(y + row * ((size_t)K8 * 32), kg * 8, src[0] * scale, src[1] * scale);
+    }
+}
+
+// max |x| of n floats -> *out (a non-negative float compared as an unsigned integer; *out must be zero before the launch)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+struct Fh2Tile { int bm, bn, occ; double eff; };
+// 256x128 with 16 waves (4x4, 3 stages of 48 KB, one workgroup per CU) and 128x64 with 8 waves (4x2, two workgroups per CU) for
+// launches whose tile count quantises badly on 256 CUs.
+static const Fh2Tile kFh2Tiles[2] = {{256, 128, 1, 1.0}, {128, 64, 2, 0.85}};
+
+static int choose_fh2_tile(int M, int N, int groups) {
+    if (const char* f = getenv("A3R_FH2_TILE")) {      // developer override: 0 | 1
+        const int t = atoi(f);
+        if (t >= 0 && t < 2) return t;
+    }
+    int best_t = 0;
+    double best = 1e300;
+    for (int t = 0; t < 2; t++) {
+        const long n = (long)((M + kFh2Tiles[t].bm - 1) / kFh2Tiles[t].bm) * ((N + kFh2Tiles[t].bn - 1) / kFh2Tiles[t].bn) * groups;
+        const long slots = 256L * kFh2Tiles[t].occ;
+        const double cost = (double)((n + slots - 1) / slots) * kFh2Tiles[t].bm * kFh2Tiles[t].bn * kFh2Tiles[t].occ / kFh2Tiles[t].eff;
+        if (cost < best * 0.999) { best = cost; best_t = t; }
+    }
+    return best_t;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool FULL>
+static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
+    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL>;
+    constexpr int lds = NS * (BM + BN) * 128;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(fa.g.tiles_per_group * fa.g.groups), dim3(WM * WN * 64), lds, st, fa);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+static int launch_fh2(Fh2Args& fa, hipStream_t st) {
+    GemmArgs& g = fa.g;
+    g.direct_epilogue = 0;
+    const int t = choose_fh2_tile(g.M, g.N, g.groups);
+    const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
+    g.tiles_m = (g.M + bm - 1) / bm;
+    g.tiles_n = (g.N + bn - 1) / bn;
+    g.tiles_per_group = g.tiles_m * g.tiles_n;
+    const bool full = g.M % bm == 0 && g.N % bn == 0;
+    const double mn = (double)g.M * g.N;
+    const double c_bytes = mn * ((g.epi.out_fh2 ? 4.0 : g.epi.out_bf3 ? 6.0 : 4.0) + (g.epi.aux_bf3 ? 6.0 : 0.0) +
+                                 (g.epi.epi == A3R_EPI_RESID ? 4.0 : g.epi.epi == A3R_EPI_RESID2 ? 8.0 : 0.0));
+    ProfScope prof(PK_LINEAR_FH2, 2.0 * g.M * g.N * g.K * g.groups, st, g.groups * (4.0 * g.M * g.K + 4.0 * g.N * g.K + c_bytes));
+    if (t == 0) return full ? launch_fh2_variant<256, 128, 4, 4, 3, true>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false>(fa, st);
+    return full ? launch_fh2_variant<128, 64, 4, 2, 3, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false>(fa, st);
+}
+
+}  // namespace a3r
+using namespace a3r;
+
+extern "C" size_t a3r_fh2_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)rows * K * 4 : 0; }
+
+extern "C" int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, void* stream) {
+    A3R_CHECK_ARG(x && y, "a3r_split_fh2: null pointer");
+    A3R_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0, "a3r_split_fh2: K (%d) must be a positive multiple of 8 (M=%ld)", K, M);
+    A3R_CHECK_ARG(ldx >= K && ldx % 4 == 0, "a3r_split_fh2: bad leading dimension %d", ldx);
+    A3R_CHECK_ARG(scale > 0.f, "a3r_split_fh2: scale must be positive");
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "a3r_split_fh2: pointers must be 16-byte aligned");
+    const long total = M * (K / 8);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PK_SPLIT, 8.0 * M * K, st);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(split_fh2_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, st, x, ldx,
+                       static_cast<char*>(y), M, K / 8, scale);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_absmax(const float* x, long n, float* out_dev, void* stream) {
+    A3R_CHECK_ARG(x && out_dev && n > 0, "a3r_absmax: bad argument");
+    hipStream_t st = as_stream(stream);
+    A3R_HIP(hipMemsetAsync(out_dev, 0, 4, st));
+    const long blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(out_dev));
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" float a3r_fh2_weight_scale(float absmax) {
+    // the power of two that puts max|w| into [2^12, 2^13): far from fp16's 65504 and with every weight above 2^-16 max|w| at full 22 bits
+    if (!(absmax > 0.f) || !std::isfinite(absmax)) return 1.f;
+    int e;
+    std::frexp(absmax, &e);                 // absmax = f 2^e, f in [0.5, 1)
+    return std::ldexp(1.f, 13 - e);
+}
+
+extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_groups, int ldc, int M, int N, int K,
+                                      const a3r_epilogue* epi, void* stream) {
+    A3R_CHECK_ARG(groups && n_groups >= 1 && n_groups <= 4, "a3r_linear_fh2_grouped: 1..4 groups required");
+    A3R_CHECK_ARG(M > 0 && N > 0 && K > 0, "a3r_linear_fh2: M, N, K must be positive (got %d, %d, %d)", M, N, K);
+    A3R_CHECK_ARG(K % 32 == 0, "a3r_linear_fh2: K (%d) must be a multiple of 32", K);
+    A3R_CHECK_ARG(ldc >= 1, "a3r_linear_fh2: bad leading dimension ldc=%d", ldc);
+    if (int rc = check_epilogue(epi, M, N, "a3r_linear_fh2", true)) return rc;
+    Fh2Args fa = {};
+    GemmArgs& g = fa.g;
+    if (epi) g.epi = *epi;
+    A3R_CHECK_ARG(!g.epi.relu_a && !g.epi.x_pair && !g.epi.out_pair, "a3r_linear_fh2: relu_a / x_pair / out_pair do not apply to fh2 operands");
+    A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF, "a3r_linear_fh2: PIXSHUF is not available");
+    if (g.epi.out_fh2) {
+        A3R_CHECK_ARG(!g.epi.out_bf3 && !g.epi.aux_bf3, "a3r_linear_fh2: out_fh2 excludes out_bf3 / aux_bf3");
+        A3R_CHECK_ARG(N % 32 == 0 && ldc == N && (g.epi.epi == A3R_EPI_NONE || g.epi.epi == A3R_EPI_GELU || g.epi.epi == A3R_EPI_RELU),
+                      "a3r_linear_fh2: out_fh2 needs N %% 32 == 0, ldc == N and a NONE / GELU / RELU epilogue");
+    }
+    for (int i = 0; i < n_groups; i++) {
+        g.grp[i] = {static_cast<const float*>(groups[i].x2), static_cast<const float*>(groups[i].w2), groups[i].y, groups[i].bias,
+                    groups[i].resid, groups[i].resid2};
+        if (int rc = check_group(g.grp[i], g.epi.epi, "a3r_linear_fh2")) return rc;
+        A3R_CHECK_ARG(groups[i].w_scale > 0.f, "a3r_linear_fh2: w_scale must be positive");
+        fa.inv_wscale[i] = 1.f / groups[i].w_scale;
+    }
+    g.groups = n_groups;
+    g.lda = K; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    A3R_CHECK_ARG(ldc >= N, "a3r_linear_fh2: ldc (%d) < N (%d)", ldc, N);
+    if (g.epi.out_bf3) A3R_CHECK_ARG(ldc == N, "a3r_linear_fh2: out_bf3 needs ldc == N");
+    return launch_fh2(fa, as_stream(stream));
+}
+
+extern "C" int a3r_linear_fh2(const void* x2, const void* w2, float w_scale, float* y, int ldc, int M, int N, int K,
+                              const a3r_epilogue* epi, void* stream) {
+    a3r_group_ptrs_fh2 p = {x2, w2, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr, w_scale};
+    return a3r_linear_fh2_grouped(&p, 1, ldc, M, N, K, epi, stream);
+}

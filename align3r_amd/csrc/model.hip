@@ -64,6 +64,10 @@ struct a3r_model_s {
     bool use_bf3 = true;
     int products = 6;         // bf3 plane products per multiply: 6 = fp32-accurate; A3R_GEMM=bf3x3 -> 3, A3R_GEMM=bf16 -> 1 (reduced precision)
     std::map<const float*, const void*> w3;
+    // transformer nn.Linear weights in fh2 form (two fp16 planes, gemm_fh2.hip) unless A3R_GEMM names another mode:
+    // fp32 pointer -> (fh2 twin in `packed`, the power-of-two scale it was stored with)
+    bool use_fh2 = true;
+    std::map<const float*, std::pair<const void*, float>> w2;
     static constexpr int MAX_POS = 256;
 };
 
@@ -84,8 +88,11 @@ extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
     m->cfg = *cfg;
     if (const char* e = getenv("A3R_GEMM")) {
         const std::string mode(e);
+        // f32: exact-fp32 MFMA kernels; bf3: every GEMM on the exact three-plane bf16 form (6 passes); bf3x3 / bf16: reduced-precision
+        // bf3 modes; anything else (default, "fh2"): transformer GEMMs on the two-plane fp16 form (3 passes), DPT convs / attention on bf3
         m->use_bf3 = mode != "f32";
         m->products = mode == "bf16" ? 1 : mode == "bf3x3" ? 3 : 6;
+        m->use_fh2 = !(mode == "f32" || mode == "bf3" || mode == "bf3x3" || mode == "bf16");
     }
     // sized here so that the host-side sizing pass (a3r_model_workspace_bytes) works before finalize
     m->enc.assign(cfg->enc_depth, BlockW());
@@ -154,12 +161,18 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
             v.push_back({n, 4, N, K, 0, off});
             off = align_up(off + a3r_bf3_w_bytes(N, K), 256);
         };
+        // kind 5: fh2 twin (+ 256 bytes behind it: scratch of the max|w| reduction that fixes its scale)
+        auto twin_lin = [&](const std::string& n, int N, int K) {
+            if (!m->use_fh2) { twin(n, N, K); return; }
+            v.push_back({n, 5, N, K, 0, off});
+            off = align_up(off + a3r_fh2_bytes(N, K) + 256, 256);
+        };
         auto block = [&](const std::string& p, int Dm, bool cross) {
-            twin(p + ".attn.qkv.weight", 3 * Dm, Dm); twin(p + ".attn.proj.weight", Dm, Dm);
-            twin(p + ".mlp.fc1.weight", Dm * c.mlp_ratio, Dm); twin(p + ".mlp.fc2.weight", Dm, Dm * c.mlp_ratio);
+            twin_lin(p + ".attn.qkv.weight", 3 * Dm, Dm); twin_lin(p + ".attn.proj.weight", Dm, Dm);
+            twin_lin(p + ".mlp.fc1.weight", Dm * c.mlp_ratio, Dm); twin_lin(p + ".mlp.fc2.weight", Dm, Dm * c.mlp_ratio);
             if (cross) {
-                twin(p + ".cross_attn.projq.weight", Dm, Dm); twin(p + ".cross_attn.kv", 2 * Dm, Dm);
-                twin(p + ".cross_attn.proj.weight", Dm, Dm);
+                twin_lin(p + ".cross_attn.projq.weight", Dm, Dm); twin_lin(p + ".cross_attn.kv", 2 * Dm, Dm);
+                twin_lin(p + ".cross_attn.proj.weight", Dm, Dm);
             }
         };
         const int E = c.enc_embed_dim;
@@ -169,10 +182,10 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
             block("dec_blocks." + std::to_string(i), D, true);
             block("dec_blocks2." + std::to_string(i), D, true);
         }
-        twin("patch_embed.proj.weight", E, 768);
-        twin("patch_embed_point_cloud.proj.weight", D, 768);
-        twin("decoder_embed.weight", D, E);
-        for (int i = 0; i <= n_pc_blocks(c); i++) twin("zero_convs." + std::to_string(i) + ".0.weight", D, D);
+        twin_lin("patch_embed.proj.weight", E, 768);
+        twin_lin("patch_embed_point_cloud.proj.weight", D, 768);
+        twin_lin("decoder_embed.weight", D, E);
+        for (int i = 0; i <= n_pc_blocks(c); i++) twin_lin("zero_convs." + std::to_string(i) + ".0.weight", D, D);
         // DPT heads: every packed 3x3 conv weight [Cout, 9 Cin] and the 1x1 out_conv of the fusion blocks
         std::vector<PackItem> convs;
         for (const PackItem& it : v)
@@ -249,7 +262,7 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
     // --- repack
     for (const PackItem& it : plan) {
         float* dst = reinterpret_cast<float*>(pk + it.off);
-        if (it.kind == 4) continue;      // after binding (shapes are validated there)
+        if (it.kind == 4 || it.kind == 5) continue;      // after binding (shapes are validated there)
         if (it.kind == 0) {
             const float* src;
             NEED(it.name, &src, it.a, it.b, 3, 3);
@@ -339,15 +352,28 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
     }
     // --- bf3 twins of the nn.Linear weights
     m->w3.clear();
+    m->w2.clear();
     for (const PackItem& it : plan) {
-        if (it.kind != 4) continue;
+        if (it.kind != 4 && it.kind != 5) continue;
         const float* src = nullptr;
         auto pit = packed_ptr.find(it.name);
         if (pit != packed_ptr.end()) src = pit->second;                 // the concatenated cross-attention k/v projection
         else src = m->w.at(it.name).p;                                   // bound (and shape-checked) above
         void* dst = pk + it.off;
-        if (int rc = a3r_split_bf3_w(src, it.b, dst, it.a, it.b, stream)) return rc;     // weights: row-pair layout (bf3.h)
-        m->w3[src] = dst;
+        if (it.kind == 4) {
+            if (int rc = a3r_split_bf3_w(src, it.b, dst, it.a, it.b, stream)) return rc;     // weights: row-pair layout (bf3.h)
+            m->w3[src] = dst;
+        } else {
+            // fh2 twin: scale = the power of two that puts max|w| into [2^12, 2^13) (one small reduction + read-back per matrix)
+            float* scratch = reinterpret_cast<float*>(pk + it.off + a3r_fh2_bytes(it.a, it.b));
+            if (int rc = a3r_absmax(src, (long)it.a * it.b, scratch, stream)) return rc;
+            float amax = 0.f;
+            A3R_HIP(hipMemcpyAsync(&amax, scratch, 4, hipMemcpyDeviceToHost, st));
+            A3R_HIP(hipStreamSynchronize(st));
+            const float scale = a3r_fh2_weight_scale(amax);
+            if (int rc = a3r_split_fh2(src, it.b, dst, it.a, it.b, scale, stream)) return rc;
+            m->w2[src] = {dst, scale};
+        }
     }
     m->finalized = true;
     return A3R_OK;
@@ -386,12 +412,17 @@ struct Plan {
     }
     // ---- "GEMM input" (gin) buffers: [rows, K] fp32 in f32 mode, the bf3 form of it (1.5x the bytes, bf3.h) otherwise
     bool bf3() const { return m->use_bf3; }
+    bool fh2() const { return m->use_bf3 && m->use_fh2; }    // transformer GEMM operands in fh2 form (attention operands stay bf3)
     // bf3 mode: buffers that are only ever read as the A operand of a GEMM (LayerNorm / attention / fc1+GELU outputs, split
     // activations) are kept in the row-pair form of the layout (bf3.h) when the row counts of both views are even
     bool pair = false;
-    float* gin_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
-    float* gin_scratch(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : 0); }     // only needed for splitting
-    template <class T> T* gin_at(T* base, size_t rows, int K) const { return base + (bf3() ? rows * K * 3 / 2 : rows * K); }
+    // (an fh2 matrix has exactly the bytes of the fp32 one)
+    float* gin_alloc(size_t rows, int K) { return ar.alloc(bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
+    float* gin_scratch(size_t rows, int K) { return ar.alloc(fh2() ? rows * K : bf3() ? rows * K * 3 / 2 : 0); }     // only needed for splitting
+    template <class T> T* gin_at(T* base, size_t rows, int K) const { return base + (bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
+    // ---- attention operands (q / k / v written by the RoPE projections): bf3 form in every bf3 / fh2 mode
+    float* att_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
+    template <class T> T* att_at(T* base, size_t rows, int K) const { return base + (bf3() ? rows * K * 3 / 2 : rows * K); }
     // column `col` (a multiple of 8) of a gin row
     const float* gin_col(const float* base, int col) const {
         return bf3() ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)col * 6) : base + col;
@@ -401,8 +432,18 @@ struct Plan {
         if (!bf3()) return x;
         if (skip()) return scratch;
         traced("split_bf3", (int)M, K);
-        rc = pair ? a3r_split_bf3_w(x, K, scratch, M, K, stream) : a3r_split_bf3(x, K, scratch, M, K, stream);
+        if (fh2()) rc = a3r_split_fh2(x, K, scratch, M, K, 1.f, stream);
+        else rc = pair ? a3r_split_bf3_w(x, K, scratch, M, K, stream) : a3r_split_bf3(x, K, scratch, M, K, stream);
         return scratch;
+    }
+    const std::pair<const void*, float>* twin2(const float* w) {
+        auto it = m->w2.find(w);
+        if (it == m->w2.end()) {
+            set_error("a3r_model_forward: nn.Linear weight without an fh2 twin");
+            rc = A3R_ESTATE;
+            return nullptr;
+        }
+        return &it->second;
     }
     const void* twin(const float* w) {
         auto it = m->w3.find(w);
@@ -418,7 +459,10 @@ struct Plan {
                 bool plain_x = false) {
         if (skip()) return;
         traced("linear", M, N, K);
-        if (bf3()) {
+        if (fh2() && !plain_x) {
+            const auto* w2 = twin2(w);
+            if (w2) rc = a3r_linear_fh2(xg, w2->first, w2->second, y, ldc, M, N, K, &e0, stream);
+        } else if (bf3()) {
             const void* w3 = twin(w);
             a3r_epilogue e = e0;
             e.x_pair = (pair && !plain_x) ? 1 : 0;
@@ -440,7 +484,12 @@ struct Plan {
                  const float* r1 = nullptr) {
         if (skip()) return;
         traced("linear2", M, N, K);
-        if (bf3()) {
+        if (fh2()) {
+            const auto *w20 = twin2(w0), *w21 = twin2(w1);
+            if (!w20 || !w21) return;
+            a3r_group_ptrs_fh2 g[2] = {{x0, w20->first, y0, b0, r0, nullptr, w20->second}, {x1, w21->first, y1, b1, r1, nullptr, w21->second}};
+            rc = a3r_linear_fh2_grouped(g, 2, ldc, M, N, K, &e, stream);
+        } else if (bf3()) {
             const void *w30 = twin(w0), *w31 = twin(w1);
             if (!w30 || !w31) return;
             a3r_group_ptrs_bf3 g[2] = {{x0, w30, y0, b0, r0, nullptr}, {x1, w31, y1, b1, r1, nullptr}};
@@ -473,7 +522,8 @@ struct Plan {
     void ln(const float* x, const float* w, const float* b, float* yg, int M, int D) {
         if (skip()) return;
         traced("layernorm", M, D);
-        rc = bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, pair, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
+        rc = fh2() ? a3r_layernorm_fh2(x, w, b, yg, M, D, 1e-6f, stream)
+                   : bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, pair, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
     }
     void ln_f32(const float* x, const float* w, const float* b, float* y, int M, int D) {
         if (skip()) return;
@@ -484,8 +534,9 @@ struct Plan {
     void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
         if (skip()) return;
         traced("attention", B, Nq, Nk);
-        rc = bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, pair, stream)
-                   : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
+        rc = fh2() ? a3r_attention_bf3_fh2out(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream)
+                   : bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, pair, stream)
+                           : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
     }
     void conv(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
         if (skip()) return;
@@ -519,6 +570,7 @@ struct Plan {
     // hid: gin [M, hidden] -- fc1's GELU epilogue writes the GEMM-input form directly (Mlp blocks.py:73-77)
     a3r_epilogue gin_epi(int kind, const float* bias) {
         a3r_epilogue e = epi(kind, bias);
+        if (fh2()) { e.out_fh2 = 1; return e; }
         e.out_bf3 = bf3() ? 1 : 0;
         e.out_pair = (bf3() && pair) ? 1 : 0;
         return e;
@@ -642,7 +694,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     Plan P;
     P.m = m; P.stream = stream;
     static const bool plain_act = getenv("A3R_BF3_PLAIN_ACT") != nullptr;      // A/B switch: keep every activation in plain rows
-    P.pair = m->use_bf3 && BN % 2 == 0 && !plain_act;
+    P.pair = m->use_bf3 && !m->use_fh2 && BN % 2 == 0 && !plain_act;
     P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};
     Arena& ar = P.ar;
     if (phase == 1) {
@@ -652,7 +704,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* cols3 = P.gin_scratch(BN, 768);
         float* x = ar.alloc((size_t)BN * E);
         float* xn = P.gin_alloc(BN, E);
-        float* qkv = P.gin_alloc(BN, 3 * E);
+        float* qkv = P.att_alloc(BN, 3 * E);
         float* att = P.gin_alloc(BN, E);
         float* hid = P.gin_alloc(BN, E * c.mlp_ratio);
         if (!dry) {
@@ -695,7 +747,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         float* cols3 = P.gin_scratch(M2, 768);
         float* x = ar.alloc((size_t)M2 * E);
         float* xn = P.gin_alloc(M2, E);
-        float* qkv = P.gin_alloc(M2, 3 * E);
+        float* qkv = P.att_alloc(M2, 3 * E);
         float* att = P.gin_alloc(M2, E);
         float* hid = P.gin_alloc(M2, E * c.mlp_ratio);
         if (!dry) {
@@ -725,9 +777,9 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         const int hidden = D * c.mlp_ratio;
         float* xn = P.gin_alloc(M2, D);
         float* yn = P.gin_alloc(M2, D);
-        float* qkv = P.gin_alloc(M2, 3 * D);
-        float* qb = P.gin_alloc(M2, D);
-        float* kv = P.gin_alloc(M2, 2 * D);
+        float* qkv = P.att_alloc(M2, 3 * D);
+        float* qb = P.att_alloc(M2, D);
+        float* kv = P.att_alloc(M2, 2 * D);
         float* att = P.gin_alloc(M2, D);
         float* hid = P.gin_alloc(M2, hidden);
         float* pc3 = P.gin_scratch(M2, D);
@@ -760,7 +812,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 P.ln(x0, w0.n1w, w0.n1b, xn, BN, D);
                 P.ln(x1, w1.n1w, w1.n1b, xn1, BN, D);
                 float* att1 = P.gin_at(att, BN, D);
-                P.linear2(xn, xn1, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, P.gin_at(qkv, BN, 3 * D), 3 * D, BN, 3 * D, D,
+                P.linear2(xn, xn1, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, P.att_at(qkv, BN, 3 * D), 3 * D, BN, 3 * D, D,
                           P.rope_epi(nullptr, 2 * D, N, nw));
                 P.attn(qkv, 3 * D, P.gin_col(qkv, D), 3 * D, P.gin_col(qkv, 2 * D), 3 * D, att, D, 2 * B, c.dec_num_heads, N, N);
                 P.linear2(att, att1, D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
@@ -770,8 +822,8 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 P.ln(x0, w1.nyw, w1.nyb, yn1, BN, D);
                 P.ln(o0, w0.n2w, w0.n2b, xn, BN, D);
                 P.ln(o1, w1.n2w, w1.n2b, xn1, BN, D);
-                P.linear2(xn, xn1, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, P.gin_at(qb, BN, D), D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
-                P.linear2(yn, yn1, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, P.gin_at(kv, BN, 2 * D), 2 * D, BN, 2 * D, D,
+                P.linear2(xn, xn1, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, P.att_at(qb, BN, D), D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
+                P.linear2(yn, yn1, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, P.att_at(kv, BN, 2 * D), 2 * D, BN, 2 * D, D,
                           P.rope_epi(nullptr, D, N, nw));
                 P.attn(qb, D, kv, 2 * D, P.gin_col(kv, D), 2 * D, att, D, 2 * B, c.dec_num_heads, N, N);
                 P.linear2(att, att1, D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
@@ -835,7 +887,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         P.linear_f32(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
         float* a3 = ar.alloc((size_t)BN * ld[3]);
         P.linear_f32(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
-        float* l3 = P.gin_alloc((size_t)B * h3 * w3, ld[3]);          // only feeds layer4_rn's conv: bf3 in bf3 mode
+        float* l3 = P.att_alloc((size_t)B * h3 * w3, ld[3]);          // only feeds layer4_rn's conv: bf3 in bf3 mode
         if (!P.bf3()) {
             P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
         } else {

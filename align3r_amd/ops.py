@@ -66,8 +66,9 @@ def layernorm(x, w, b, eps=1e-6, out=None):
 
 
 def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
-                  aux_bf3=None, aux_relu=False, out_pair=False):
+                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False):
     e = Epilogue()
+    e.out_fh2 = int(out_fh2)
     e.out_bf3 = int(out_bf3)
     e.out_pair = int(out_pair)
     e.aux_bf3 = None if aux_bf3 is None else aux_bf3.data_ptr()
@@ -238,6 +239,106 @@ def attention_bf3(q3: Bf3, k3: Bf3, v3: Bf3, B, H, Nq, Nk, q_col=0, k_col=0, v_c
     check(_lib.load().a3r_attention_bf3(q3.data_ptr() + q_col * 6, q3.K, k3.data_ptr() + k_col * 6, k3.K, v3.data_ptr() + v_col * 6, v3.K,
                                         o3.data_ptr(), H * 64, B, H, Nq, Nk, int(out_pair), stream_ptr()), "attention_bf3")
     return o3
+
+
+# ------------------------------------------------------------------------------------------------- fh2 (two fp16 planes)
+class Fh2:
+    """An fp32 matrix [rows, K] in fh2 form (two fp16 planes of scale * x, include/a3r.h): uint8 storage + shape + scale."""
+
+    def __init__(self, data: torch.Tensor, rows: int, K: int, scale: float = 1.0):
+        self.data, self.rows, self.K, self.scale = data, rows, K, float(scale)
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def planes(self):
+        """-> float32 [2, rows, K]: the two planes (of scale * x)."""
+        u = self.data.view(torch.float16).view(self.rows, self.K // 8, 2, 8)
+        return u.permute(2, 0, 1, 3).reshape(2, self.rows, self.K).float()
+
+    def value(self):
+        """float64 [rows, K]: (h0 + h1) / scale."""
+        p = self.planes().double()
+        return (p[0] + p[1]) / self.scale
+
+
+def fh2_weight_scale(w) -> float:
+    """The power of two a3r_model_finalize would store these weights with (max|w| -> [2^12, 2^13))."""
+    lib = _lib.load()
+    out = torch.zeros(1, device=w.device, dtype=torch.float32)
+    check(lib.a3r_absmax(ptr(_req(w, "w")), w.numel(), ptr(out), stream_ptr()), "absmax")
+    return float(lib.a3r_fh2_weight_scale(float(out.item())))
+
+
+def split_fh2(x, scale=1.0) -> Fh2:
+    """fp32 x [..., K] -> fh2 of scale * x (a3r_split_fh2)."""
+    _req(x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K
+    y = torch.empty(M * K * 4, device=x.device, dtype=torch.uint8)
+    check(_lib.load().a3r_split_fh2(ptr(x), K, ptr(y), M, K, float(scale), stream_ptr()), "split_fh2")
+    return Fh2(y, M, K, scale)
+
+
+def split_fh2_w(w) -> Fh2:
+    """Weights [N, K] -> fh2 with the automatic power-of-two scale."""
+    return split_fh2(w, fh2_weight_scale(w))
+
+
+def layernorm_fh2(x, w, b, eps=1e-6) -> Fh2:
+    _req(x, "x")
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty(M * D * 4, device=x.device, dtype=torch.uint8)
+    check(_lib.load().a3r_layernorm_fh2(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(y), M, D, eps, stream_ptr()), "layernorm_fh2")
+    return Fh2(y, M, D)
+
+
+def linear_fh2(x2: Fh2, w2: Fh2, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
+    """nn.Linear on the fp16 matrix cores with fp32-GEMM accuracy: x2 [M, K] (scale 1), w2 [N, K] in fh2 form (a3r_linear_fh2).
+    out_fh2=True returns an Fh2, out_bf3=True a Bf3 (the attention kernel's operand format), otherwise fp32 [M, N]."""
+    M, K, N = x2.rows, x2.K, w2.rows
+    if w2.K != K:
+        raise RuntimeError(f"linear_fh2: K mismatch ({K} vs {w2.K})")
+    if x2.scale != 1.0:
+        raise RuntimeError("linear_fh2: the activation operand must have scale 1")
+    e = make_epilogue(epi, bias, **kw)
+    dev = x2.data.device
+    if e.out_fh2:
+        y = Fh2(torch.zeros(M * N * 4, device=dev, dtype=torch.uint8), M, N)
+        check(_lib.load().a3r_linear_fh2(x2.data_ptr(), w2.data_ptr(), w2.scale, y.data_ptr(), N, M, N, K, C.byref(e), stream_ptr()), "linear_fh2")
+        return y
+    if e.out_bf3:
+        y = Bf3(torch.zeros(M * N * 6, device=dev, dtype=torch.uint8), M, N)
+        check(_lib.load().a3r_linear_fh2(x2.data_ptr(), w2.data_ptr(), w2.scale, y.data_ptr(), N, M, N, K, C.byref(e), stream_ptr()), "linear_fh2")
+        return y
+    if out is None:
+        out = torch.empty((M, N), device=dev, dtype=torch.float32)
+    check(_lib.load().a3r_linear_fh2(x2.data_ptr(), w2.data_ptr(), w2.scale, ptr(out), out.shape[-1], M, N, K, C.byref(e), stream_ptr()), "linear_fh2")
+    return out
+
+
+def linear_fh2_grouped(x2s, w2s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
+    G = len(x2s)
+    M, K, N = x2s[0].rows, x2s[0].K, w2s[0].rows
+    outs = [torch.empty((M, N), device=x2s[0].data.device, dtype=torch.float32) for _ in range(G)]
+    arr = (_lib.GroupPtrsFh2 * G)()
+    for i in range(G):
+        arr[i].x, arr[i].w, arr[i].y = x2s[i].data_ptr(), w2s[i].data_ptr(), outs[i].data_ptr()
+        arr[i].bias = None if biases is None else biases[i].data_ptr()
+        arr[i].resid = None if resids is None else resids[i].data_ptr()
+        arr[i].w_scale = w2s[i].scale
+    e = make_epilogue(epi, **kw)
+    check(_lib.load().a3r_linear_fh2_grouped(arr, G, N, M, N, K, C.byref(e), stream_ptr()), "linear_fh2_grouped")
+    return outs
+
+
+def attention_bf3_fh2out(q3: Bf3, k3: Bf3, v3: Bf3, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0) -> Fh2:
+    """attention_bf3 with the output written in fh2 form (the input of an fh2 output projection)."""
+    o2 = Fh2(torch.zeros(B * Nq * H * 64 * 4, device=q3.data.device, dtype=torch.uint8), B * Nq, H * 64)
+    check(_lib.load().a3r_attention_bf3_fh2out(q3.data_ptr() + q_col * 6, q3.K, k3.data_ptr() + k_col * 6, k3.K, v3.data_ptr() + v_col * 6,
+                                               v3.K, o2.data_ptr(), H * 64, B, H, Nq, Nk, stream_ptr()), "attention_bf3_fh2out")
+    return o2
 
 
 def pack_conv3x3(w):

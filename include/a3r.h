@@ -110,6 +110,9 @@ typedef struct {
      * A matrix with an odd number of rows occupies (rows + 1) * K * 6 bytes in this form (a3r_bf3_w_bytes). */
     int x_pair;
     int out_pair;
+    /* a3r_linear_fh2 only: write y in fh2 form ([M][N/8][2][8] fp16, N % 32 == 0, ldc = N) instead of fp32, for outputs that only
+     * feed the next a3r_linear_fh2 (Mlp: fc1 + GELU -> fc2, blocks.py:73-77).  NONE / GELU / RELU. */
+    int out_fh2;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
@@ -169,6 +172,36 @@ typedef struct {
 int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int ldc, int M, int N, int K,
                            const a3r_epilogue* epi, void* stream);
 
+/* ---- the same nn.Linear on the fp16 matrix cores, fp32-GEMM-accurate ("fh2" operands)
+ * An fp32 matrix X [R, K] (K % 32 == 0) in fh2 form is two fp16 planes, s X ~ X0 + X1 (X0 = rn_f16(s X), X1 = rn_f16(s X - X0)), laid
+ * out [R][K/8][2][8] fp16 (4 K bytes per row, a3r_fh2_bytes), with s a power of two: 1 for activations, a3r_fh2_weight_scale(max|w|)
+ * for weights.  a3r_linear_fh2 evaluates x0 w0 + x0 w1 + x1 w0 -- three fp16 MFMA passes, every product exact in the fp32
+ * accumulator -- so the operands carry 22 of fp32's 24 significant bits; against float64 the result is as accurate as a3r_linear's
+ * (the fp32 accumulation error dominates: tests/test_gpu_fh2.py) at half the matrix passes of a3r_linear_bf3.
+ * Same call sites as a3r_linear (blocks.py:58-169); epilogues as above (no PIXSHUF), out_bf3 for the projections that feed the
+ * attention kernel, out_fh2 for fc1 + GELU -> fc2. */
+size_t a3r_fh2_bytes(long rows, int K);
+/* fp32 x [M, ldx] (first K columns) * scale -> fh2 y (K % 8 == 0) */
+int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, void* stream);
+/* max |x| over n floats -> *out_dev (device float; the call zeroes it first) and the weight scale derived from it (host helper) */
+int a3r_absmax(const float* x, long n, float* out_dev, void* stream);
+float a3r_fh2_weight_scale(float absmax);
+/* nn.LayerNorm (as a3r_layernorm) writing its output in fh2 form (scale 1; D % 32 == 0) */
+int a3r_layernorm_fh2(const float* x, const float* w, const float* b, void* y2, int M, int D, float eps, void* stream);
+typedef struct {
+    const void* x2;       /* fh2 [M, K], scale 1 */
+    const void* w2;       /* fh2 [N, K], stored with w_scale */
+    float* y;
+    const float* bias;
+    const float* resid;
+    const float* resid2;
+    float w_scale;
+} a3r_group_ptrs_fh2;
+int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_groups, int ldc, int M, int N, int K, const a3r_epilogue* epi,
+                           void* stream);
+int a3r_linear_fh2(const void* x2, const void* w2, float w_scale, float* y, int ldc, int M, int N, int K, const a3r_epilogue* epi,
+                   void* stream);
+
 /* nn.Conv2d(k=3, padding=1, stride in {1,2}) as an implicit GEMM on the bf3 kernel: x3 = bf3 form of the channels-last map
  * [B, H, W, Cin] (i.e. of the [B H W, Cin] matrix), wp3 = bf3 form of the packed weights [Cout, 9 Cin] (a3r_pack_conv3x3
  * then a3r_split_bf3_w); y [B, Ho, Wo, Cout] fp32 (or bf3 with out_bf3).  Same call sites as a3r_conv3x3 (dpt_block.py). */
@@ -195,6 +228,9 @@ int a3r_attention(const float* q, int ldq, const float* k, int ldk, const float*
  * q3 / k3 / v3 are always plain rows). */
 int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o3, int ldo,
                       int B, int H, int Nq, int Nk, int out_pair, void* stream);
+/* the same, writing o in fh2 form (scale 1, plain rows, ldo % 8 == 0): the input of an a3r_linear_fh2 output projection */
+int a3r_attention_bf3_fh2out(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o2, int ldo,
+                             int B, int H, int Nq, int Nk, void* stream);
 
 /* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
  * HOST buffers. */

@@ -1,0 +1,100 @@
+"""GPU: the fh2 kernels (two fp16 planes, three MFMA passes: include/a3r.h, csrc/fh2.h) through the C ABI.
+  * the split is what the header says: planes are fp16(s x) and fp16(s x - h0); the represented value is within 2^-22 |x| of x
+    (or 2^-25 / s where h1 is subnormal);
+  * a3r_linear_fh2 against float64: its error is not larger than the exact-fp32 MFMA kernel's (the fp32 accumulation error
+    dominates), every tile shape, ragged shapes, every epilogue incl. RoPE -> bf3 and GELU -> fh2;
+  * producers (LayerNorm, attention output, GELU epilogue) write exactly the split of their fp32 result."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from align3r_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from align3r_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def test_split_fh2_is_the_documented_split(ops):
+    x = rnd(37, 96, seed=1, scale=3.0)
+    x[0, :8] = torch.tensor([0.0, 1e-3, -2e-5, 7e-7, 100.0, -3000.0, 0.124, -0.126]).cuda()
+    for scale in (1.0, 16.0):
+        f = ops.split_fh2(x, scale)
+        p = f.planes()
+        xs = (x * scale)
+        h0 = xs.half().float()
+        h1 = (xs - h0).half().float()
+        assert torch.equal(p[0], h0) and torch.equal(p[1], h1)
+        err = (f.value() - x.double()).abs()
+        bound = torch.maximum(x.double().abs() * 2.0 ** -22, torch.full_like(err, 2.0 ** -25 / scale))
+        assert bool((err <= bound * 1.0001).all())
+
+
+@pytest.mark.parametrize("tile", ["0", "1"])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (300, 200, 96), (1000, 384, 1024), (256, 128, 4096)])
+def test_linear_fh2_error_not_larger_than_fp32_mfma(ops, monkeypatch, tile, M, N, K):
+    """max |err| / sum|a||b| against float64: fh2 (22-bit operands, exact products, fp32 accumulate) vs the exact-fp32 MFMA GEMM."""
+    monkeypatch.setenv("A3R_FH2_TILE", tile)
+    x, w, b = rnd(M, K, seed=1, scale=2.0), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = x.double() @ w.double().T + b.double()
+    den = x.double().abs() @ w.double().abs().T + b.double().abs()
+    y2 = ops.linear_fh2(ops.split_fh2(x), ops.split_fh2_w(w), b)
+    y32 = ops.linear(x, w, b)
+    e2 = float(((y2.double() - ref).abs() / den).max())
+    e32 = float(((y32.double() - ref).abs() / den).max())
+    assert e2 < 3e-7 and e2 <= 1.5 * e32 + 1e-8, (e2, e32)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 96), (256, 256, 64)])
+def test_linear_fh2_epilogues(ops, M, N, K):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    x2, w2 = ops.split_fh2(x), ops.split_fh2_w(w)
+    base = ops.linear_fh2(x2, w2, b)
+    tol = lambda a, c: float((a - c).abs().max() / c.abs().max())
+    assert tol(base, ops.linear(x, w, b)) < 2e-6
+    assert tol(ops.linear_fh2(x2, w2, b, epi=_lib.EPI_RESID, resid=r), base + r) < 1e-6
+    assert tol(ops.linear_fh2(x2, w2, b, epi=_lib.EPI_GELU), torch.nn.functional.gelu(base)) < 1e-6
+    # GELU -> fh2: exactly the split of the fp32 GELU output
+    g2 = ops.linear_fh2(x2, w2, b, epi=_lib.EPI_GELU, out_fh2=True)
+    want = ops.split_fh2(ops.linear_fh2(x2, w2, b, epi=_lib.EPI_GELU))
+    assert torch.equal(g2.planes(), want.planes())
+    # NONE -> bf3 (the attention operand format): exactly the bf3 split of the fp32 output
+    y3 = ops.linear_fh2(x2, w2, b, out_bf3=True)
+    assert torch.equal(y3.planes(), ops.split_bf3(base).planes())
+    # grouped launch == two single launches
+    w2b = ops.split_fh2_w(rnd(N, K, seed=7, scale=K ** -0.5))
+    outs = ops.linear_fh2_grouped([x2, x2], [w2, w2b], [b, b])
+    assert torch.equal(outs[0], base) and torch.equal(outs[1], ops.linear_fh2(x2, w2b, b))
+
+
+def test_layernorm_fh2_vs_float64(ops):
+    """LayerNorm -> fh2: the represented values against a float64 LayerNorm (the lane -> element mapping differs from the fp32
+    kernel's, so the statistics are summed in another order: fp32-level agreement, not bitwise), and against the fp32 kernel."""
+    for M, D in [(10, 1024), (333, 768), (7, 64), (64, 256)]:
+        x, w, b = rnd(M, D, seed=1, scale=2.0), rnd(D, seed=2), rnd(D, seed=3)
+        got = ops.layernorm_fh2(x, w, b).value()
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+        f32 = ops.layernorm(x, w, b).double()
+        assert float((got - f32).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_attention_fh2_output_is_the_split_of_the_bf3_one(ops):
+    B, H, Nq, Nk = 3, 2, 77, 50
+    q, k, v = (rnd(B * n, H * 64, seed=s) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    args = (ops.split_bf3(q), ops.split_bf3(k), ops.split_bf3(v), B, H, Nq, Nk)
+    o3 = ops.attention_bf3(*args).planes().sum(0)                 # exact fp32 value of the bf3 output
+    o2 = ops.attention_bf3_fh2out(*args)
+    assert torch.equal(o2.planes(), ops.split_fh2(o3.contiguous()).planes())
