@@ -1,0 +1,249 @@
+// Flash-style attention for head_dim 64 on the fp16 matrix cores from two-plane fp16 operands ("fh2", fh2.h).
+//
+// Replaces  attn = softmax(q @ k^T * hd^-0.5); x = attn @ v   of
+//   Attention.forward      croco/models/blocks.py:105-109
+//   CrossAttention.forward croco/models/blocks.py:164-168
+// like attention_bf3.hip, with every product evaluated as THREE exact fp16 x fp16 MFMA passes (h0 g0 + h0 g1 + h1 g0) instead of
+// six bf16 ones: q, k, v arrive in fh2 form from the projection GEMM (RoPE + out_fh2 epilogue, gemm_fh2.hip), S^T = K Q^T and
+// O^T = V^T P^T run on v_mfma_f32_32x32x16_f16, the online softmax is fp32 on the accumulators, and P -- in [0, 1] -- is split into
+// two fp16 planes of 1024 p in registers (22 significant bits down to p = 2^-13, absolute error 2^-35 below that) and used directly
+// as the B operand; the factor 1024 is divided out with the softmax normaliser.  O is written in fh2 form for the output
+// projection.  Structure, staging and LDS layouts as attention_bf3.hip (K tiles by LDS-DMA into a double buffer, V tiles through
+// registers into a transposed, key-permuted image, two 32-key online-softmax blocks per 64-key tile); the two-plane images are
+// 53 KB per workgroup, so THREE workgroups of 4 waves share a CU.
+#include "common.h"
+#include "fh2.h"
+
+namespace a3r {
+
+constexpr int A4T = 256;                    // threads per workgroup (4 waves, 32 queries each)
+constexpr int A4Q = 128;                    // queries per workgroup
+constexpr int A4K = 64;                     // keys per tile
+constexpr int A4_KUNITS = 17;               // K row: 16 units (8 d-groups x 2 planes) + 1 pad unit (an odd stride: conflict-free b128 reads)
+constexpr int A4_KROW = A4_KUNITS * 16;
+constexpr int A4_KSLOTS = A4K * A4_KUNITS;  // 1088 DMA slots per tile
+constexpr int A4KI = (A4_KSLOTS + A4T - 1) / A4T;   // 5 per thread, the last one only on wave 0
+constexpr int A4VI = (A4K * 16) / A4T;      // 4 V units per thread
+constexpr int A4_KS_BYTES = A4K * A4_KROW;  // one K tile (two of them)
+constexpr int A4_VROW = 9 * 16;             // V^T row: 64 keys x 2 B + 1 pad unit
+constexpr int A4_VT_BYTES = 2 * 64 * A4_VROW;   // V^T tile: 2 planes x 64 d
+constexpr int A4_LDS_BYTES = 2 * A4_KS_BYTES + A4_VT_BYTES;   // 53,248 B
+constexpr float A4_PSCALE = 1024.f;
+
+struct Attn4Args {
+    const char *q, *k, *v;
+    char* o;
+    size_t pq, pk, pv, po;                  // row pitches in bytes (4 x leading dimension)
+    int B, H, Nq, Nk;
+};
+
+typedef const __attribute__((address_space(1))) void* a4_gptr;
+typedef __attribute__((address_space(3))) void* a4_lptr;
+typedef uint32_t a4_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                // [2][64 rows][17 units]
+    char* Vt = smem + 2 * A4_KS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, half = lane >> 5;
+    // XCD-aware mapping: all query blocks of one (batch, head) land on ONE XCD
+    const int nqb = (a.Nq + A4Q - 1) / A4Q;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int group = (seq / nqb) * 8 + xcd, qb = seq - (seq / nqb) * nqb;
+    if (group >= a.B * a.H) return;                 // uniform per workgroup
+    const int h = group % a.H, b = group / a.H;
+    const int q_row = qb * A4Q + wave * 32 + qi;
+    const int q_ld = q_row < a.Nq ? q_row : a.Nq - 1;
+
+    // Q operand (B of S^T = K Q^T): lane (query, half) holds, per 16-deep d-step s and plane p, unit (2 s + half) 2 + p of its head
+    f16x8 qf[4][2];
+    {
+        const char* qp = a.q + ((size_t)b * a.Nq + q_ld) * a.pq + h * 256;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) qf[s][p] = *reinterpret_cast<const f16x8*>(qp + ((2 * s + half) * 2 + p) * 16);
+    }
+
+    // ---- staging
+    // K: LDS-DMA of 64 x 17 = 1088 slots (4 per thread + one more on wave 0); slot u = (row u / 17, unit u % 17), the pad unit
+    //    re-reads unit 0.  V: 1024 units through registers, 4 per thread; unit u -> (key = u & 63 = tid & 63,
+    //    gp = u >> 6 = 2 d-group + plane): a wave walks the keys of one (d-group, plane).
+    const char* kbase = a.k + (size_t)b * a.Nk * a.pk + h * 256;
+    const char* vbase = a.v + (size_t)b * a.Nk * a.pv + h * 256;
+    auto issue_k = [&](int k0, int buf) {
+        char* base = Ks + buf * A4_KS_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < A4KI; i++) {
+            if (i == A4KI - 1 && wave != 0) break;                // slots 1024..1087: one wave
+            const int u = min(tid + A4T * i, A4_KSLOTS - 1);
+            const int row = (u * 3856) >> 16;                     // u / 17 for u < 1088
+            const int cu = u - row * 17;
+            const int kk = min(k0 + row, a.Nk - 1);               // keys past Nk: finite copies, masked to -inf below
+            __builtin_amdgcn_global_load_lds((a4_gptr)(kbase + (size_t)kk * a.pk + (cu == 16 ? 0 : cu) * 16),
+                                             (a4_lptr)(base + A4T * 16 * i), 16, 0, 0);
+        }
+    };
+    // V^T position of this thread's key: pos = 32 kt + 16 s2 + 8 hh + j with t = key & 15: hh = (t >> 2) & 1,
+    // j = (t & 3) + 4 (t >> 3)   (the order the S^T accumulator holds its keys)
+    const int vkey = tid & 63, vt = vkey & 15;
+    const int vpos2 = ((vkey & 48) + ((vt >> 2) & 1) * 8 + (vt & 3) + 4 * (vt >> 3)) * 2;
+    a4_u32x4 rv[A4VI];
+    auto load_v = [&](int k0) {
+        const int vk = min(k0 + vkey, a.Nk - 1);
+        const char* src = vbase + (size_t)vk * a.pv + wave * 16;
+#pragma unroll
+        for (int i = 0; i < A4VI; i++) rv[i] = *reinterpret_cast<const a4_u32x4*>(src + 4 * 16 * i);      // gp = wave + 4 i
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < A4VI; i++) {
+            const int gp = wave + 4 * i, g = gp >> 1, p = gp & 1;                                        // wave-uniform
+            char* dst = Vt + (p * 64 + 8 * g) * A4_VROW + vpos2;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t w = rv[i][j >> 1];
+                *reinterpret_cast<uint16_t*>(dst + j * A4_VROW) = (j & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffffu);
+            }
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) oacc[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float SCALE_LOG2E = 0.125f * 1.4426950408889634f;     // hd^-0.5 folded into the exp2 argument
+
+    const int kfrag = qi * A4_KROW + half * 32;       // this lane's K operand: row qi (+32 kb), units (2 st + half) 2 + p
+    const int vfrag = qi * A4_VROW + half * 16;       // this lane's V^T operand: row d = qi (+32 db), unit 4 kb + 2 s2 + half
+    const int ntiles = (a.Nk + A4K - 1) / A4K;
+    issue_k(0, 0);
+    load_v(0);
+    store_v();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int k0 = t * A4K;
+        if (t + 1 < ntiles) {
+            issue_k(k0 + A4K, (t + 1) & 1);        // that buffer was last read in iteration t-1: every wave has passed a barrier since
+            load_v(k0 + A4K);
+        }
+        const char* Kt = Ks + (t & 1) * A4_KS_BYTES;
+        // two 32-key blocks, each a full online-softmax step (keeps one score tile live at a time)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            // ---- S^T = K Q^T
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                f16x8 kf[2];
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+                    kf[p] = *reinterpret_cast<const f16x8*>(Kt + kfrag + kb * 32 * A4_KROW + st * 64 + p * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[st][0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[st][1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[st][0], s, 0, 0, 0);
+            }
+            // ---- online softmax (keys of this lane: k0 + 32 kb + (e&3) + 8*(e>>2) + 4*half)
+            if (k0 + kb * 32 + 32 > a.Nk) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (key >= a.Nk) s[e] = -INFINITY;
+                }
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; e++) mx = fmaxf(mx, s[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);        // finite: block kb = 0 of every tile has a valid key, and m_run carries it on
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
+            m_run = m_new;
+            float lsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float p = __builtin_amdgcn_exp2f((s[e] - m_new) * SCALE_LOG2E);
+                s[e] = p;
+                lsum += p;
+            }
+            l_run = l_run * alpha + lsum;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {          // the running max moved for some query of this wave (rare after the first tiles)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) oacc[i][e] *= alpha;
+            }
+            // ---- O^T += V^T P^T: split 1024 P into two fp16 planes (k-step s2 = accumulator elements 8 s2 .. 8 s2 + 7)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                a4_u32x4 pf[2];
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) {
+                    uint32_t p0, p1;
+                    fh2_split2(s[8 * s2 + 2 * mm] * A4_PSCALE, s[8 * s2 + 2 * mm + 1] * A4_PSCALE, p0, p1);
+                    pf[0][mm] = p0; pf[1][mm] = p1;
+                }
+                const f16x8 b0 = __builtin_bit_cast(f16x8, pf[0]), b1 = __builtin_bit_cast(f16x8, pf[1]);
+#pragma unroll
+                for (int db = 0; db < 2; db++) {
+                    f16x8 vf[2];
+#pragma unroll
+                    for (int p = 0; p < 2; p++)
+                        vf[p] = *reinterpret_cast<const f16x8*>(Vt + vfrag + (p * 64 + db * 32) * A4_VROW + (kb * 4 + s2 * 2) * 16);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], b0, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], b1, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], b0, oacc[db], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                       // every wave is done with this tile's V^T image
+        if (t + 1 < ntiles) store_v();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K DMAs for tile t+1 have landed
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.f / (l_tot * A4_PSCALE);            // the P planes carried the factor 1024 (an exact power of two)
+    if (q_row < a.Nq) {
+        // lane (query, half) holds d = 32 db + 8 g + 4 half + (0..3): half of each plane's unit
+        char* op = a.o + ((size_t)b * a.Nq + q_row) * a.po;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = {oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l, oacc[db][4 * g + 2] * inv_l,
+                                 oacc[db][4 * g + 3] * inv_l};
+                fh2_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v);
+            }
+    }
+}
+
+}  // namespace a3r
+using namespace a3r;
+
+extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ldk, const void* v2, int ldv, void* o2, int ldo,
+                                 int B, int H, int Nq, int Nk, void* stream) {
+    A3R_CHECK_ARG(q2 && k2 && v2 && o2, "a3r_attention_fh2: null pointer");
+    A3R_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "a3r_attention_fh2: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    A3R_CHECK_ARG(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ldo >= H * 64, "a3r_attention_fh2: row strides < H*64");
+    A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_fh2: row strides must be multiples of 8");
+    A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q2) | reinterpret_cast<uintptr_t>(k2) | reinterpret_cast<uintptr_t>(v2) |
+                    reinterpret_cast<uintptr_t>(o2)) & 15) == 0, "a3r_attention_fh2: pointers must be 16-byte aligned");
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES));
+    }
+    Attn4Args a = {static_cast<const char*>(q2), static_cast<const char*>(k2), static_cast<const char*>(v2), static_cast<char*>(o2),
+                   (size_t)ldq * 4, (size_t)ldk * 4, (size_t)ldv * 4, (size_t)ldo * 4, B, H, Nq, Nk};
+    const int nqb = (Nq + A4Q - 1) / A4Q, groups = B * H;
+    dim3 grid(8 * ((groups + 7) / 8) * nqb);
+    ProfScope prof(PK_ATTENTION_FH2, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
+    hipLaunchKernelGGL(attn_fh2_kernel, grid, dim3(A4T), A4_LDS_BYTES, as_stream(stream), a);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}

@@ -58,9 +58,15 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
     for (int half = 0; half < TM / 2; half++) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int col = n0 + wcol0 + j * 16 + lcol;
+            const int colbase = n0 + wcol0 + j * 16;
+            const int col = colbase + lcol;
             const bool col_ok = FULL || col < g.N;
             const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
+            // 2-D RoPE on the leading rope_cols columns (pairs (d, d + 16) inside each 32-wide half of a head, pos_embed.py:130-157):
+            // the partner column is accumulator tile j ^ 1 of the same lane
+            const bool do_rope = ep.epi == A3R_EPI_ROPE && colbase < ep.rope_cols;       // wave-uniform (rope_cols % 64 == 0)
+            const float bias_o = (do_rope && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] : 0.f;
+            const bool rope_x = (colbase & 32) != 0, second = (colbase & 16) != 0;
             const int cw = j * 16 + lcol;
             char* dcol = img + (cw >> 3) * 32 + (cw & 7) * 2;
 #pragma unroll
@@ -68,11 +74,27 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     const int i = half * 2 + il;
-                    float v0 = acc[i][j][e] + bias, v1 = acc[i][j][e + 1] + bias;
-                    if (ep.epi == A3R_EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); }
-                    else if (ep.epi == A3R_EPI_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    float v[2];
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        v[d] = acc[i][j][e + d] + bias;
+                        if (do_rope) {
+                            const int row = m0 + wrow0 + i * 16 + quad * 4 + e + d;
+                            const float other = acc[i][j ^ 1][e + d] + bias_o;
+                            const int tok = row % ep.tokens_per_image;
+                            const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
+                            const int pp = rope_x ? px : py;
+                            const float c = ep.rope_cos[pp * 16 + lcol], sn = ep.rope_sin[pp * 16 + lcol];
+                            // one rounding order for every element (a product, then one fused multiply-add): hipcc otherwise vectorises
+                            // the row pair and contracts its two halves differently, i.e. a row's result depends on its parity
+                            const float t = __fmul_rn(other, sn);
+                            v[d] = __fmaf_rn(v[d], c, second ? t : -t);
+                        }
+                        if (ep.epi == A3R_EPI_GELU) v[d] = gelu_erf(v[d]);
+                        else if (ep.epi == A3R_EPI_RELU) v[d] = fmaxf(v[d], 0.f);
+                    }
                     uint32_t p0, p1;
-                    fh2_split2(v0, v1, p0, p1);                  // low half: row e, high half: row e + 1
+                    fh2_split2(v[0], v[1], p0, p1);                  // low half: row e, high half: row e + 1
                     char* d = dcol + (il * 16 + quad * 4 + e) * EPI_FH2_PITCH;
                     *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
                     *reinterpret_cast<uint16_t*>(d + 16) = (uint16_t)p1;
@@ -336,8 +358,9 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
     A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF, "a3r_linear_fh2: PIXSHUF is not available");
     if (g.epi.out_fh2) {
         A3R_CHECK_ARG(!g.epi.out_bf3 && !g.epi.aux_bf3, "a3r_linear_fh2: out_fh2 excludes out_bf3 / aux_bf3");
-        A3R_CHECK_ARG(N % 32 == 0 && ldc == N && (g.epi.epi == A3R_EPI_NONE || g.epi.epi == A3R_EPI_GELU || g.epi.epi == A3R_EPI_RELU),
-                      "a3r_linear_fh2: out_fh2 needs N %% 32 == 0, ldc == N and a NONE / GELU / RELU epilogue");
+        A3R_CHECK_ARG(N % 32 == 0 && ldc == N && (g.epi.epi == A3R_EPI_NONE || g.epi.epi == A3R_EPI_GELU || g.epi.epi == A3R_EPI_RELU ||
+                                                  g.epi.epi == A3R_EPI_ROPE),
+                      "a3r_linear_fh2: out_fh2 needs N %% 32 == 0, ldc == N and a NONE / GELU / RELU / ROPE epilogue");
     }
     for (int i = 0; i < n_groups; i++) {
         g.grp[i] = {static_cast<const float*>(groups[i].x2), static_cast<const float*>(groups[i].w2), groups[i].y, groups[i].bias,

@@ -420,12 +420,14 @@ struct Plan {
     float* gin_alloc(size_t rows, int K) { return ar.alloc(bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
     float* gin_scratch(size_t rows, int K) { return ar.alloc(fh2() ? rows * K : bf3() ? rows * K * 3 / 2 : 0); }     // only needed for splitting
     template <class T> T* gin_at(T* base, size_t rows, int K) const { return base + (bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
-    // ---- attention operands (q / k / v written by the RoPE projections): bf3 form in every bf3 / fh2 mode
-    float* att_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
-    template <class T> T* att_at(T* base, size_t rows, int K) const { return base + (bf3() ? rows * K * 3 / 2 : rows * K); }
+    // ---- attention operands (q / k / v written by the RoPE projections): fh2 in fh2 mode, bf3 in the bf3 modes
+    float* att_alloc(size_t rows, int K) { return ar.alloc(bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
+    template <class T> T* att_at(T* base, size_t rows, int K) const { return base + (bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
+    // maps that are only ever conv inputs (DPT): bf3 form in every bf3 / fh2 mode
+    float* map_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
     // column `col` (a multiple of 8) of a gin row
     const float* gin_col(const float* base, int col) const {
-        return bf3() ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)col * 6) : base + col;
+        return bf3() && !fh2() ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)col * 6) : base + col;
     }
     // fp32 activation -> GEMM input: a split pass into `scratch` in bf3 mode, the array itself otherwise
     const float* gin_from(const float* x, float* scratch, long M, int K) {
@@ -534,7 +536,7 @@ struct Plan {
     void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
         if (skip()) return;
         traced("attention", B, Nq, Nk);
-        rc = fh2() ? a3r_attention_bf3_fh2out(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream)
+        rc = fh2() ? a3r_attention_fh2(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream)
                    : bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, pair, stream)
                            : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
     }
@@ -551,7 +553,8 @@ struct Plan {
     // projection feeding attention: RoPE on the leading columns, output in gin form
     a3r_epilogue rope_epi(const float* bias, int rope_cols, int ntok, int gw) {
         a3r_epilogue e = epi(A3R_EPI_ROPE, bias);
-        e.out_bf3 = bf3() ? 1 : 0;
+        if (fh2()) e.out_fh2 = 1;
+        else e.out_bf3 = bf3() ? 1 : 0;
         e.rope_cols = rope_cols; e.tokens_per_image = ntok; e.grid_w = gw;
         e.rope_cos = m->rope_cos; e.rope_sin = m->rope_sin;
         return e;
@@ -887,7 +890,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         P.linear_f32(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
         float* a3 = ar.alloc((size_t)BN * ld[3]);
         P.linear_f32(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
-        float* l3 = P.att_alloc((size_t)B * h3 * w3, ld[3]);          // only feeds layer4_rn's conv: bf3 in bf3 mode
+        float* l3 = P.map_alloc((size_t)B * h3 * w3, ld[3]);          // only feeds layer4_rn's conv: bf3 in bf3 mode
         if (!P.bf3()) {
             P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
         } else {

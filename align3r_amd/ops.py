@@ -333,6 +333,15 @@ def linear_fh2_grouped(x2s, w2s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
     return outs
 
 
+def attention_fh2(q2: Fh2, k2: Fh2, v2: Fh2, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0) -> Fh2:
+    """softmax(q k^T / 8) v per head (head_dim 64) on fh2 operands (a3r_attention_fh2); q2/k2/v2 may be column slices (start column,
+    multiple of 8) of wider fh2 matrices.  Returns the fh2 [B*Nq, H*64] output."""
+    o2 = Fh2(torch.zeros(B * Nq * H * 64 * 4, device=q2.data.device, dtype=torch.uint8), B * Nq, H * 64)
+    check(_lib.load().a3r_attention_fh2(q2.data_ptr() + q_col * 4, q2.K, k2.data_ptr() + k_col * 4, k2.K, v2.data_ptr() + v_col * 4, v2.K,
+                                        o2.data_ptr(), H * 64, B, H, Nq, Nk, stream_ptr()), "attention_fh2")
+    return o2
+
+
 def attention_bf3_fh2out(q3: Bf3, k3: Bf3, v3: Bf3, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0) -> Fh2:
     """attention_bf3 with the output written in fh2 form (the input of an fh2 output projection)."""
     o2 = Fh2(torch.zeros(B * Nq * H * 64 * 4, device=q3.data.device, dtype=torch.uint8), B * Nq, H * 64)

@@ -178,29 +178,41 @@ def main():
         dt = float(t.item())
     pairs_per_s = world * B * a.steps / dt
     byname = {p["name"]: p for p in prof}
-    lin_bf3 = byname.get("gemm_bf3_kernel (linear, split-bf16 MFMA)")
-    use_bf3 = bool(lin_bf3 and lin_bf3["launches"])
-    lin = lin_bf3 if use_bf3 else byname["gemm_kernel<0> (linear)"]
+    # roofline of the DOMINANT matrix-core kernel class (largest share of the timed region).  Ceiling for ALGORITHMIC fp32 FLOP =
+    # dense fp16 / bf16 MFMA peak / (matrix passes per fp32 product): fh2 evaluates 3 fp16 passes, bf3 6 bf16 passes; the
+    # exact-fp32 kernel is priced against the fp32 MFMA peak.
+    mfma_classes = {
+        "gemm_fh2_kernel (linear, split-fp16 MFMA)": dict(
+            passes=3, pmc="gemm_fh2_kernel", desc="gemm_fh2_kernel (nn.Linear on the fp16 matrix cores: two-plane fp16 split of both fp32 "
+            "operands = 22-bit operands, 3 exact fp16 MFMA passes, fp32 accumulate)"),
+        "gemm_bf3_kernel (linear, split-bf16 MFMA)": dict(
+            passes=6, pmc="gemm_bf3_kernel", desc="gemm_bf3_kernel (nn.Linear on the bf16 matrix cores: exact 3-plane split of both fp32 "
+            "operands, 6 bf16 MFMA passes, fp32 accumulate)"),
+        "gemm_kernel<0> (linear)": dict(passes=0, pmc="gemm_kernel<0>", desc="gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)"),
+    }
+    lin_name = max(mfma_classes, key=lambda n: byname[n]["ms"] if n in byname else -1.0)
+    lin, cls = byname[lin_name], mfma_classes[lin_name]
+    use_split = cls["passes"] > 0
     achieved = lin["work"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
-    # roofline of the dominant kernel.  fp32 MFMA kernel: algorithmic fp32 FLOP against the fp32 MFMA peak.  bf3 kernel: it
-    # executes SIX bf16 MFMA flops per algorithmic fp32 flop, so its ceiling for ALGORITHMIC flops is bf16 peak / 6.
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if use_bf3 else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS / cls["passes"] if use_split else PEAK_F32_MFMA_TFLOPS
+    mode = os.environ.get("A3R_GEMM", "fh2")
     kernels = {p["name"]: dict(launches=p["launches"], total_ms=round(p["ms"], 3),
                                avg_us=round(1e3 * p["ms"] / p["launches"], 2) if p["launches"] else None,
                                rate=round(p["work"] / (p["ms"] * 1e-3) / 1e12, 3) if p["ms"] > 0 else None)
                for p in prof if p["launches"]}
     flop_pair = FLOP_PER_PAIR.get((H, W))
-    lin_traffic, lin_traffic_src = (pmc_traffic("gemm_bf3_kernel" if use_bf3 else "gemm_kernel<0>") if (B, H, W) == (42, 384, 512)
-                                    else (None, None))
+    lin_traffic, lin_traffic_src = pmc_traffic(cls["pmc"]) if (B, H, W) == (42, 384, 512) else (None, None)
     lin_bytes = lin.get("bytes", 0.0) / max(lin["launches"], 1)
     res = {
         "metric": "frame-pairs/s ViT-L 512px + global-align iters/s, 1/2/4/8 MI355X", "value": round(pairs_per_s, 4),
         "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "dtype_note": ("fp32 in / fp32 out / fp32 accumulate; products evaluated exactly from three-plane bf16 splits of both operands on the "
-                       "bf16 matrix cores (6 MFMA passes, error <= fp32 GEMM's: tests/test_gpu_bf3.py); A3R_GEMM=f32 selects v_mfma_f32_32x32x2_f32"
-                       if use_bf3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+        "dtype": "f32", "data": "synthetic", "gemm_mode": mode,
+        "dtype_note": ("fp32 in / fp32 out / fp32 accumulate.  Transformer GEMMs (A3R_GEMM=fh2, default): both operands split into two fp16 "
+                       "planes (22 significant bits), 3 exact fp16 MFMA passes -- error vs float64 not larger than the exact-fp32 MFMA GEMM's "
+                       "(tests/test_gpu_fh2.py); attention products and DPT convolutions: exact three-plane bf16 splits, 6 bf16 MFMA passes "
+                       "(tests/test_gpu_bf3.py).  A3R_GEMM=bf3 runs every GEMM on the exact three-plane form, A3R_GEMM=f32 on "
+                       "v_mfma_f32_32x32x2_f32"),
         "config": {"workload": f"{a.frames}-frame synthetic clip {W}x{H}, ViT-L, {a.scene_graph} symmetrised (E={E}), "
                                f"{B} pairs/step/GPU, cloud_opt PointCloudOptimizer", "pairs_per_step_per_gpu": B,
                    "frames": a.frames, "edges": E, "parallelism": f"pair-shard x{world}" + (" + all-gather/step" if world > 1 else "")},
@@ -209,14 +221,13 @@ def main():
                               "count -- the plan runs each DPT fusion block's 1x1 out_conv before the bilinear 2x (a quarter of the rows), "
                               "so it executes ~0.7 % fewer FLOP than the reference for the same result"),
         "rccl_ranks": rccl_ranks,
-        "roofline": {"bound": "mfma",
-                     "kernel": ("gemm_bf3_kernel (nn.Linear on the bf16 matrix cores: exact 3-plane split of both fp32 operands, "
-                                "6 bf16 MFMA passes, fp32 accumulate)" if use_bf3 else "gemm_kernel<0> (fp32 MFMA GEMM, all nn.Linear)"),
+        "roofline": {"bound": "mfma", "kernel": cls["desc"],
                      "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "peak_note": ("bf16 dense MFMA peak 2500 / 6 passes = ceiling for algorithmic fp32 FLOP; executed bf16 MFMA rate = "
-                                   f"{6 * achieved:.0f} TFLOP/s; the exact-fp32 MFMA peak is {PEAK_F32_MFMA_TFLOPS}" if use_bf3
+                     "peak_note": (f"dense fp16/bf16 MFMA peak 2500 / {cls['passes']} passes = ceiling for algorithmic fp32 FLOP; executed MFMA rate = "
+                                   f"{cls['passes'] * achieved:.0f} TFLOP/s; the exact-fp32 MFMA peak is {PEAK_F32_MFMA_TFLOPS}" if use_split
                                    else "v_mfma_f32_32x32x2_f32 dense peak"),
                      "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     "share_of_step": round(lin["ms"] / (1e3 * dt), 3),
                      "traffic": lin_traffic, "traffic_source": lin_traffic_src,
                      "algorithmic_bytes_per_launch": round(lin_bytes) if lin_bytes else None,
                      "traffic_over_algorithmic": round(lin_traffic / lin_bytes, 2) if (lin_traffic and lin_bytes) else None,

@@ -179,7 +179,7 @@ int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int l
  * accumulator -- so the operands carry 22 of fp32's 24 significant bits; against float64 the result is as accurate as a3r_linear's
  * (the fp32 accumulation error dominates: tests/test_gpu_fh2.py) at half the matrix passes of a3r_linear_bf3.
  * Same call sites as a3r_linear (blocks.py:58-169); epilogues as above (no PIXSHUF), out_bf3 for the projections that feed the
- * attention kernel, out_fh2 for fc1 + GELU -> fc2. */
+ * attention kernel, out_fh2 (NONE / GELU / RELU / ROPE) for fc1 + GELU -> fc2 and for the q / k / v of a3r_attention_fh2. */
 size_t a3r_fh2_bytes(long rows, int K);
 /* fp32 x [M, ldx] (first K columns) * scale -> fh2 y (K % 8 == 0) */
 int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, void* stream);
@@ -231,6 +231,13 @@ int a3r_attention_bf3(const void* q3, int ldq, const void* k3, int ldk, const vo
 /* the same, writing o in fh2 form (scale 1, plain rows, ldo % 8 == 0): the input of an a3r_linear_fh2 output projection */
 int a3r_attention_bf3_fh2out(const void* q3, int ldq, const void* k3, int ldk, const void* v3, int ldv, void* o2, int ldo,
                              int B, int H, int Nq, int Nk, void* stream);
+
+/* The same attention on the fp16 matrix cores from fh2 operands (q2 / k2 / v2 / o2: fh2 matrices, pointers to the first column's
+ * 32-byte group, leading dimensions in fp32 columns, multiples of 8): three exact fp16 MFMA passes per product, fp32 softmax,
+ * P split into two fp16 planes of 1024 p in registers.  Consumes the RoPE + out_fh2 output of a3r_linear_fh2 and produces the fh2
+ * input of the output projection. */
+int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ldk, const void* v2, int ldv, void* o2, int ldo,
+                      int B, int H, int Nq, int Nk, void* stream);
 
 /* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
  * HOST buffers. */

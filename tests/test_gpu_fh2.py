@@ -98,3 +98,38 @@ def test_attention_fh2_output_is_the_split_of_the_bf3_one(ops):
     o3 = ops.attention_bf3(*args).planes().sum(0)                 # exact fp32 value of the bf3 output
     o2 = ops.attention_bf3_fh2out(*args)
     assert torch.equal(o2.planes(), ops.split_fh2(o3.contiguous()).planes())
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 32, 64), (2, 3, 196, 196), (1, 2, 768, 768), (2, 2, 100, 37), (1, 12, 576, 576), (1, 1, 300, 65)])
+def test_attention_fh2(ops, B, H, Nq, Nk):
+    """softmax(q k^T / 8) v on fh2 operands (blocks.py:105-109,164-168) vs float64: fp32-level error, not larger than the exact
+    three-plane bf16 kernel's by more than rounding; fused-qkv column slices included."""
+    D = H * 64
+    q, k, v = rnd(B * Nq, D, seed=1), rnd(B * Nk, D, seed=2), rnd(B * Nk, D, seed=3)
+    qd, kd, vd = (t.double().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / 8.0, -1) @ vd).transpose(1, 2).reshape(B * Nq, D)
+    o2 = ops.attention_fh2(ops.split_fh2(q), ops.split_fh2(k), ops.split_fh2(v), B, H, Nq, Nk)
+    e2 = float((o2.value() - ref).abs().max() / ref.abs().max())
+    o3 = ops.attention_bf3(ops.split_bf3(q), ops.split_bf3(k), ops.split_bf3(v), B, H, Nq, Nk)
+    e3 = float((o3.planes().double().sum(0) - ref).abs().max() / ref.abs().max())
+    assert e2 < 2e-6 and e2 < 3 * e3 + 2e-7, (e2, e3)
+    if Nq == Nk:      # the self-attention layout: one [rows, 3 D] fh2 matrix, q / k / v are column slices
+        qkv2 = ops.split_fh2(torch.cat([q, k, v], 1).contiguous())
+        o2b = ops.attention_fh2(qkv2, qkv2, qkv2, B, H, Nq, Nk, q_col=0, k_col=D, v_col=2 * D)
+        assert torch.equal(o2b.data, o2.data)
+
+
+def test_linear_fh2_rope_to_fh2(ops):
+    """The q / k projection epilogue: RoPE-2D on the leading columns, written in fh2 form, against the fp32-output epilogue of the same
+    kernel and against the exact-fp32 MFMA GEMM's."""
+    for M, N, K in [(50, 192, 96), (300, 384, 128)]:
+        x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+        x2, w2 = ops.split_fh2(x), ops.split_fh2_w(w)
+        cos, sin = ops.rope_tables(x.device)
+        for rope_cols in (N, N - 64):
+            got = ops.linear_fh2(x2, w2, b, epi=_lib.EPI_ROPE, rope=(rope_cols, 25, 5, cos, sin), out_fh2=True).value()
+            want = ops.linear_fh2(x2, w2, b, epi=_lib.EPI_ROPE, rope=(rope_cols, 25, 5, cos, sin)).double()
+            # (the two epilogues contract the rotation's multiply-adds differently: fp32-level agreement, not bitwise)
+            assert float((got - want).abs().max() / want.abs().max()) < 1e-6, (M, N, K, rope_cols)
+            ref = ops.linear(x, w, b, epi=_lib.EPI_ROPE, rope=(rope_cols, 25, 5, cos, sin)).double()
+            assert float((got - ref).abs().max() / ref.abs().max()) < 3e-6
