@@ -16,6 +16,7 @@
 #include "gemm_common.h"
 #include "fh2.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace a3r {
 
@@ -36,6 +37,7 @@ __device__ __forceinline__ void fh2_wait_vmcnt_dyn(int n) {
 struct Fh2Args {
     GemmArgs g;
     float inv_wscale[4];      // per group: 1 / (power-of-two scale the weights were stored with)
+    int lab;                  // developer experiment (A3R_FH2_LAB): 1 = every tile LOADS operand tiles (m & 1, n & 1) -- all L2 hits
 };
 
 __device__ __forceinline__ int fh2_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
@@ -117,15 +119,15 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_fh2_kernel(Fh2Args fa) {
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, bool PIPE, int LAB = 0>
+__global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4) void gemm_fh2_kernel(Fh2Args fa) {
     const GemmArgs& g = fa.g;
     constexpr int NT = WM * WN * 64, U = 8;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int SA = BM * U, SB = BN * U;                                 // 16-byte units per stage
     static_assert(SA % NT == 0 && SB % NT == 0, "whole DMA rounds");
     constexpr int LA = SA / NT, LB = SB / NT, LPS = LA + LB;               // DMAs per thread per stage
-    static_assert(WTN == 32 && WTM % 32 == 0, "wave tiles are 32 columns wide (epilogues) and multiples of 32 rows");
+    static_assert(WTN % 32 == 0 && WTM % 32 == 0, "wave tiles are multiples of 32 columns (epilogue blocks) and of 32 rows");
     constexpr int STAGE = (SA + SB) * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -149,13 +151,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_fh2_kernel(Fh2Args fa) {
 #pragma unroll
     for (int i = 0; i < LA; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
-        const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
+        const int lm0 = fa.lab == 1 ? (tile_m & 1) * BM : m0;
+        const int gm = FULL ? lm0 + r : min(lm0 + r, g.M - 1);     // rows past M are computed on a copy of the last row, never stored
         srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + (j ^ fh2_swz(r)) * 16;
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
-        const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
+        const int ln0 = fa.lab == 1 ? (tile_n & 1) * BN : n0;
+        const int gn = FULL ? ln0 + r : min(ln0 + r, g.N - 1);
         srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + (j ^ fh2_swz(r)) * 16;
     }
     auto issue = [&](int kt, int buf) {
@@ -168,14 +172,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_fh2_kernel(Fh2Args fa) {
             __builtin_amdgcn_global_load_lds((fh2_gptr)(srcB[i] + koff), (fh2_lptr)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
     };
     const int nk = g.K / 32;
-    auto acquire = [&](int kt) {
-        const int rem = nk - 1 - kt, fly = rem < NS - 2 ? rem : NS - 2;
-        fh2_wait_vmcnt_dyn(fly * LPS);
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
-    };
-    for (int t = 0; t < NS - 1 && t < nk; t++) issue(t, t);
-
     constexpr int TM = WTM / 16, TN = WTN / 16;
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -193,6 +189,79 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_fh2_kernel(Fh2Args fa) {
         offA[p] = ((wm * WTM + frow) * U + c) * 16;
         offB[p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
     }
+    if constexpr (PIPE) {
+        // Software-pipelined form: the fragments of k-step kt+1 are read from LDS WHILE the matrix cores work on k-step kt.  The A
+        // fragments roll in place (row i's registers are reloaded right after row i's MFMAs are issued), the B fragments are double
+        // buffered by k-step parity.  Ring: on entry to k-step kt stage kt is in registers, stage kt+1 is waited for (own DMAs, then
+        // the barrier covers everybody's), its buffer is read during the step, and the DMA of stage kt+NS goes into stage kt's
+        // buffer (every wave's reads of it completed before the barrier): NS-1 stages stay in flight behind the one being read.
+        const int npro = nk < NS ? nk : NS;
+        for (int t = 0; t < npro; t++) issue(t, t);
+        fh2_wait_vmcnt_dyn((npro - 1) * LPS);
+        __builtin_amdgcn_s_barrier();
+        f16x8 af[TM][2], bfr[2][TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(smem + offA[p] + i * 16 * U * 16);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) bfr[0][j][p] = *reinterpret_cast<const f16x8*>(smem + offB[p] + j * 16 * U * 16);
+        int nbuf = 1 % NS;                                         // ring slot of stage kt + 1
+        auto kstep = [&](int kt, f16x8 (&bc)[TN][2], f16x8 (&bn)[TN][2], auto has_next) {
+            constexpr bool NEXT = decltype(has_next)::value;
+            const char* sb = smem + nbuf * STAGE;
+            if constexpr (NEXT) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): stage kt is in registers: its buffer may be overwritten after the barrier
+                if (kt + NS <= nk) fh2_wait_vmcnt<(NS - 2) * LPS>();
+                else fh2_wait_vmcnt_dyn((nk - kt - 2) * LPS);
+                __builtin_amdgcn_s_barrier();
+                if (kt + NS < nk && LAB != 3 && LAB != 4 && (LAB != 5 || (wave >> 2) == 0)) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) bn[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) {                     // smallest terms first
+                    if constexpr (LAB == 2 || LAB == 4) { acc[i][j][0] += (float)af[i][1][0] + (float)bc[j][1][0] + (float)af[i][0][1] + (float)bc[j][0][1]; continue; }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
+                }
+                if constexpr (NEXT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LAB == 5 && i + 1 < 4 && (wave >> 2) == i + 1 && kt + NS < nk) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
+#pragma unroll
+                    for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(sb + offA[p] + i * 16 * U * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            kstep(kt, bfr[0], bfr[1], std::true_type{});
+            kstep(kt + 1, bfr[1], bfr[0], std::true_type{});
+        }
+        if (kt + 1 < nk) {
+            kstep(kt, bfr[0], bfr[1], std::true_type{});
+            kstep(kt + 1, bfr[1], bfr[0], std::false_type{});
+        } else {
+            kstep(kt, bfr[0], bfr[1], std::false_type{});
+        }
+    } else {
+    auto acquire = [&](int kt) {
+        const int rem = nk - 1 - kt, fly = rem < NS - 2 ? rem : NS - 2;
+        fh2_wait_vmcnt_dyn(fly * LPS);
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+    };
+    for (int t = 0; t < NS - 1 && t < nk; t++) issue(t, t);
     for (int kt = 0; kt < nk; kt++) {
         acquire(kt);
         const char* sb = smem + (kt % NS) * STAGE;
@@ -215,23 +284,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_fh2_kernel(Fh2Args fa) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
     }
+    }
     // undo the weight scale (an exact power of two), then the shared epilogues
     const float inv = fa.inv_wscale[grp];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = acc[i][j] * inv;
-    static_assert(NS * STAGE >= WM * WN * epi_lds_wave_bytes(WTM), "the LDS epilogue image fits in the stage ring");
-    if (g.epi.out_fh2) {                                       // wave-uniform
-        __syncthreads();                                       // every wave is done reading the last stage
-        fh2_epilogue_out<TM, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane, smem + wave * EPI_FH2_WAVE_BYTES);
-    } else if (epilogue16_lds_ok(g, P)) {
-        __syncthreads();
-        gemm_epilogue16_lds<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane,
-                                          reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)));
-    } else {
-        gemm_epilogue16<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
-    }
+    // (the launch allocates max(stage ring, epilogue images) bytes of LDS)
+    // the epilogues work on 32-column blocks of the wave tile
+    const bool to_fh2 = g.epi.out_fh2, via_lds = !to_fh2 && epilogue16_lds_ok(g, P);       // wave-uniform
+    if (to_fh2 || via_lds) __syncthreads();                    // every wave is done reading the last stage
+    auto block = [&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        f32x4 blk[TM][2];
+#pragma unroll
+        for (int i = 0; i < TM; i++) { blk[i][0] = acc[i][2 * cb]; blk[i][1] = acc[i][2 * cb + 1]; }
+        const int wcol = wn * WTN + cb * 32;
+        if (to_fh2) fh2_epilogue_out<TM, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane, smem + wave * EPI_FH2_WAVE_BYTES);
+        else if (via_lds)
+            gemm_epilogue16_lds<TM, 2, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane, reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)));
+        else gemm_epilogue16<TM, 2, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane);
+    };
+    block(std::integral_constant<int, 0>{});
+    if constexpr (TN >= 4) block(std::integral_constant<int, 1>{});
+    if constexpr (TN >= 6) block(std::integral_constant<int, 2>{});
+    if constexpr (TN >= 8) block(std::integral_constant<int, 3>{});
 }
 
 // fp32 [M, ldx] -> fh2 [M][K/8][2][8]: one thread per group of 8 consecutive k (32 B in, 32 contiguous bytes out)
@@ -254,18 +332,21 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 struct Fh2Tile { int bm, bn, occ; double eff; };
-// 256x128 with 16 waves (4x4, 3 stages of 48 KB, one workgroup per CU) and 128x64 with 8 waves (4x2, two workgroups per CU) for
-// launches whose tile count quantises badly on 256 CUs.
-static const Fh2Tile kFh2Tiles[2] = {{256, 128, 1, 1.0}, {128, 64, 2, 0.85}};
+// 0: 256x128, 16 waves (4x4), 3 stages of 48 KB, one workgroup per CU.   1: 128x64, 8 waves (4x2), two workgroups per CU, for launches
+// whose tile count quantises badly.   2: 128x128, 8 waves (2x4), 2 stages of 32 KB, TWO workgroups per CU -- one workgroup's epilogue
+// (and its barrier waits) run under the other's matrix work: +4 % over tile 0 on the forward's shapes although it moves 1.33x the
+// operand bytes per flop (same-call A/B, tools/bench_fh2.py).   3: 256x128 with 8 waves of 64x64 (a third fewer LDS fragment reads,
+// 224 VGPRs): 17 % slower (two waves per SIMD hide neither the barrier nor the longer per-wave epilogue); kept for A3R_FH2_TILE=3.
+static const Fh2Tile kFh2Tiles[4] = {{256, 128, 1, 0.96}, {128, 64, 2, 0.82}, {128, 128, 2, 1.0}, {256, 128, 1, 0.0}};
 
 static int choose_fh2_tile(int M, int N, int groups) {
     if (const char* f = getenv("A3R_FH2_TILE")) {      // developer override: 0 | 1
         const int t = atoi(f);
-        if (t >= 0 && t < 2) return t;
+        if (t >= 0 && t < 4) return t;
     }
     int best_t = 0;
     double best = 1e300;
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < 3; t++) {
         const long n = (long)((M + kFh2Tiles[t].bm - 1) / kFh2Tiles[t].bm) * ((N + kFh2Tiles[t].bn - 1) / kFh2Tiles[t].bn) * groups;
         const long slots = 256L * kFh2Tiles[t].occ;
         const double cost = (double)((n + slots - 1) / slots) * kFh2Tiles[t].bm * kFh2Tiles[t].bn * kFh2Tiles[t].occ / kFh2Tiles[t].eff;
@@ -274,10 +355,10 @@ static int choose_fh2_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL>
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, bool PIPE, int LAB = 0>
 static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
-    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL>;
-    constexpr int lds = NS * (BM + BN) * 128;
+    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, PIPE, LAB>;
+    constexpr int ring = NS * (BM + BN) * 128, epi = WM * WN * epi_lds_wave_bytes(BM / WM), lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
@@ -291,18 +372,36 @@ static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
 static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     GemmArgs& g = fa.g;
     g.direct_epilogue = 0;
+    if (const char* l = getenv("A3R_FH2_LAB")) fa.lab = atoi(l);
     const int t = choose_fh2_tile(g.M, g.N, g.groups);
     const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
     g.tiles_per_group = g.tiles_m * g.tiles_n;
-    const bool full = g.M % bm == 0 && g.N % bn == 0;
+    const bool full = g.M % bm == 0 && g.N % bn == 0 && !getenv("A3R_FH2_NOFULL");
     const double mn = (double)g.M * g.N;
     const double c_bytes = mn * ((g.epi.out_fh2 ? 4.0 : g.epi.out_bf3 ? 6.0 : 4.0) + (g.epi.aux_bf3 ? 6.0 : 0.0) +
                                  (g.epi.epi == A3R_EPI_RESID ? 4.0 : g.epi.epi == A3R_EPI_RESID2 ? 8.0 : 0.0));
     ProfScope prof(PK_LINEAR_FH2, 2.0 * g.M * g.N * g.K * g.groups, st, g.groups * (4.0 * g.M * g.K + 4.0 * g.N * g.K + c_bytes));
-    if (t == 0) return full ? launch_fh2_variant<256, 128, 4, 4, 3, true>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false>(fa, st);
-    return full ? launch_fh2_variant<128, 64, 4, 2, 3, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false>(fa, st);
+    static const bool pipe = !(getenv("A3R_FH2_PIPE") && atoi(getenv("A3R_FH2_PIPE")) == 0);
+    if (t == 0) {
+#ifdef A3R_FH2_LABS                                        // component-isolation experiments (wrong results by design): make CXXFLAGS+=-DA3R_FH2_LABS
+        if (full && pipe && fa.lab >= 2) {
+            switch (fa.lab) {
+                case 2: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 2>(fa, st);
+                case 3: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 3>(fa, st);
+                case 4: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 4>(fa, st);
+                case 5: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 5>(fa, st);
+            }
+        }
+#endif
+        if (pipe) return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, true>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, true>(fa, st);
+        return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, false>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, false>(fa, st);
+    }
+    if (t == 3) return full ? launch_fh2_variant<256, 128, 4, 2, 3, true, true>(fa, st) : launch_fh2_variant<256, 128, 4, 2, 3, false, true>(fa, st);
+    if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, true>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, true>(fa, st);
+    if (pipe) return full ? launch_fh2_variant<128, 64, 4, 2, 3, true, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false, true>(fa, st);
+    return full ? launch_fh2_variant<128, 64, 4, 2, 3, true, false>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false, false>(fa, st);
 }
 
 }  // namespace a3r

@@ -42,7 +42,7 @@ def test_split_fh2_is_the_documented_split(ops):
         assert bool((err <= bound * 1.0001).all())
 
 
-@pytest.mark.parametrize("tile", ["0", "1"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
 @pytest.mark.parametrize("M,N,K", [(512, 256, 128), (300, 200, 96), (1000, 384, 1024), (256, 128, 4096)])
 def test_linear_fh2_error_not_larger_than_fp32_mfma(ops, monkeypatch, tile, M, N, K):
     """max |err| / sum|a||b| against float64: fh2 (22-bit operands, exact products, fp32 accumulate) vs the exact-fp32 MFMA GEMM."""
