@@ -21,7 +21,7 @@ class Epilogue(C.Structure):
                 ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
                 ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int),
-                ("out_fh2", C.c_int)]
+                ("out_fh2", C.c_int), ("aux_fh2", c_void)]
 
 
 class GroupPtrs(C.Structure):
@@ -104,6 +104,8 @@ SIGNATURES = {
     "a3r_patchify": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, c_void]),
     "a3r_upsample2x": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_upsample2x_bf3": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_upsample2x_fh2": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_conv3x3_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_head_final": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_long, C.c_int, c_void]),
     "a3r_model_create": (C.c_int, [C.POINTER(ModelConfigC), C.POINTER(c_void)]),
     "a3r_model_destroy": (C.c_int, [c_void]),

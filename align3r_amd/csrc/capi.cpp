@@ -37,7 +37,8 @@ static const char* g_names[PK_COUNT] = {"gemm_kernel<0> (linear)", "gemm_kernel<
                                         "elementwise (patchify/upsample/head_final/pack)", "align_main_kernel",
                                         "align_finalize/prep kernels", "gemm_bf3_kernel (linear, split-bf16 MFMA)",
                                         "split_bf3_kernel", "gemm_bf3_kernel<1> (conv3x3, split-bf16 MFMA)",
-                                        "attn_bf3_kernel", "gemm_fh2_kernel (linear, split-fp16 MFMA)", "attn_fh2_kernel"};
+                                        "attn_bf3_kernel", "gemm_fh2_kernel (linear, split-fp16 MFMA)", "attn_fh2_kernel",
+                                        "gemm_fh2_kernel<1> (conv3x3, split-fp16 MFMA)"};
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;

@@ -38,7 +38,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---- optional per-kernel timing with HIP events on the launch stream (a3r_prof_* in include/a3r.h)
-enum ProfKernel { PK_LINEAR = 0, PK_CONV, PK_ATTENTION, PK_LAYERNORM, PK_ELEMENTWISE, PK_ALIGN_MAIN, PK_ALIGN_SMALL, PK_LINEAR_BF3, PK_SPLIT, PK_CONV_BF3, PK_ATTENTION_BF3, PK_LINEAR_FH2, PK_ATTENTION_FH2, PK_COUNT };
+enum ProfKernel { PK_LINEAR = 0, PK_CONV, PK_ATTENTION, PK_LAYERNORM, PK_ELEMENTWISE, PK_ALIGN_MAIN, PK_ALIGN_SMALL, PK_LINEAR_BF3, PK_SPLIT, PK_CONV_BF3, PK_ATTENTION_BF3, PK_LINEAR_FH2, PK_ATTENTION_FH2, PK_CONV_FH2, PK_COUNT };
 bool prof_enabled();
 void prof_begin(int kernel, double work, hipStream_t st, double bytes = 0);
 void prof_end(hipStream_t st);

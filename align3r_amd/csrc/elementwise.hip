@@ -246,7 +246,8 @@ __global__ void patchify_kernel(const float* __restrict__ img, float* __restrict
 // ------------------------------------------------------------------------------------------- bilinear x2, align_corners=True
 // Index arithmetic in fp32 exactly as ATen's upsample_bilinear2d (scale = (in-1)/(out-1); src = scale*dst).
 // BF3: write the result in bf3 form (rows = output pixels, K = C) -- the input of the following 1x1 / 3x3 conv on the bf3 kernel.
-template <bool BF3>
+// FMT 0: fp32, 1: bf3, 2: fh2 output
+template <int FMT>
 __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
                                   int Hc, int Wc) {
     const float sh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
@@ -269,7 +270,8 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
         const f32x4 v00 = xv[((rb + y0) * W + x0) * C4 + c], v01 = xv[((rb + y0) * W + x1) * C4 + c];
         const f32x4 v10 = xv[((rb + y1) * W + x0) * C4 + c], v11 = xv[((rb + y1) * W + x1) * C4 + c];
         const f32x4 o = (v00 * lx0 + v01 * lx1) * ly0 + (v10 * lx0 + v11 * lx1) * ly1;
-        if (BF3) bf3_store4(reinterpret_cast<char*>(y) + (i / C4) * ((size_t)C4 * 24), c * 4, o);
+        if (FMT == 1) bf3_store4(reinterpret_cast<char*>(y) + (i / C4) * ((size_t)C4 * 24), c * 4, o);
+        else if (FMT == 2) fh2_store4(reinterpret_cast<char*>(y) + (i / C4) * ((size_t)C4 * 16), c * 4, o);
         else yv[i] = o;
     }
 }
@@ -505,7 +507,7 @@ extern "C" int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
+    hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -516,7 +518,19 @@ extern "C" int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W,
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_bf3: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 24.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y3), B, H, W,
+    hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y3), B, H, W,
+                       C / 4, Hc, Wc);
+    A3R_LAUNCH_CHECK();
+    return A3R_OK;
+}
+
+extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W, int C, int Hc, int Wc, void* stream) {
+    A3R_CHECK_ARG(x && y2, "a3r_upsample2x_fh2: null pointer");
+    A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "a3r_upsample2x_fh2: bad shape (C must be a multiple of 8)");
+    A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_fh2: crop window larger than the 2x map");
+    const long total = (long)B * Hc * Wc * (C / 4);
+    ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
+    hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
                        C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "bf3.h"
+#include "fh2.h"
 
 namespace a3r {
 
@@ -311,6 +312,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
     __builtin_amdgcn_wave_barrier();
     // ---- phase 2: one float4 of one row per lane: residuals, fp32 store, the auxiliary bf3 form
     char* out3 = O3 == 0 ? nullptr : static_cast<char*>(ep.aux_bf3);
+    char* out2 = static_cast<char*>(ep.aux_fh2);              // the auxiliary output in fh2 form (fh2 kernels)
     const bool relu3 = ep.aux_relu;
     const int r_in = lane / LPR, c4 = (lane % LPR) * 4;
     const int gcol = n0 + wcol0 + c4;
@@ -326,9 +328,10 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
         if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) v += *reinterpret_cast<const f32x4*>(P.resid + o);
         if (epi == A3R_EPI_RESID2) v += *reinterpret_cast<const f32x4*>(P.resid2 + o);
         *reinterpret_cast<f32x4*>(P.C + o) = v;
-        if (out3) {
+        if (out3 || out2) {
             if (relu3) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            bf3_store4(out3 + bf3_row_offset(grow, g.N, 0), gcol, v, 0);
+            if (out3) bf3_store4(out3 + bf3_row_offset(grow, g.N, 0), gcol, v, 0);
+            else fh2_store4(out2 + (size_t)grow * fh2_row_bytes(g.N), gcol, v);
         }
     }
 }

@@ -40,6 +40,9 @@ struct Fh2Args {
     int lab;                  // developer experiment (A3R_FH2_LAB): 1 = every tile LOADS operand tiles (m & 1, n & 1) -- all L2 hits
 };
 
+// all-zero source for the padding taps of the implicit conv (LDS-DMA has no predicated zero fill)
+__device__ __attribute__((aligned(16))) unsigned int g_fh2_zero[4];
+
 __device__ __forceinline__ int fh2_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
 
 // ---- out_fh2 epilogue: bias / GELU / ReLU in the accumulator layout, the two fp16 planes go to a wave-private LDS image shaped like
@@ -119,7 +122,7 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL, bool PIPE, int LAB = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, int LAB = 0, int AMODE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4) void gemm_fh2_kernel(Fh2Args fa) {
     const GemmArgs& g = fa.g;
     constexpr int NT = WM * WN * 64, U = 8;
@@ -146,14 +149,34 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const size_t pitch = fh2_row_bytes(g.K);
-    const char* srcA[LA];
+    // AMODE 0: A is an fh2 matrix [M, K].  AMODE 1: implicit 3x3 conv (padding 1, stride 1 or 2) over an fh2 channels-last map
+    // x [B, H, W, Cin]: row m of A is output pixel m, its K axis is (tap, ci) -- stage kt covers 32 channels of ONE tap, i.e. one
+    // 128-byte line of one input pixel, or zeros where the tap falls into the padding.
+    const char* srcA[LA];       // AMODE 0: row pointer at k = 0; AMODE 1: the centre tap's pixel, channel 0
+    int tapsA[LA];              // AMODE 1: bit t set <=> tap t = 3 dy + dx lies inside the map
     const char* srcB[LB];
 #pragma unroll
     for (int i = 0; i < LA; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
         const int lm0 = fa.lab == 1 ? (tile_m & 1) * BM : m0;
         const int gm = FULL ? lm0 + r : min(lm0 + r, g.M - 1);     // rows past M are computed on a copy of the last row, never stored
-        srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + (j ^ fh2_swz(r)) * 16;
+        if (AMODE == 0) {
+            srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + (j ^ fh2_swz(r)) * 16;
+            tapsA[i] = 0;
+        } else {
+            const int hw = g.cHo * g.cWo;
+            const int b = gm / hw, rem = gm - b * hw;
+            const int oy = rem / g.cWo, ox = rem - oy * g.cWo;
+            const int iy = oy * g.cStride, ix = ox * g.cStride;     // centre tap
+            srcA[i] = reinterpret_cast<const char*>(P.A) + (((size_t)b * g.cH + iy) * g.cW + ix) * ((size_t)g.cCin * 4) + (j ^ fh2_swz(r)) * 16;
+            int mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int yy = iy + t / 3 - 1, xx = ix + t % 3 - 1;
+                if (yy >= 0 && yy < g.cH && xx >= 0 && xx < g.cW) mask |= 1 << t;
+            }
+            tapsA[i] = mask;
+        }
     }
 #pragma unroll
     for (int i = 0; i < LB; i++) {
@@ -162,11 +185,24 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
         const int gn = FULL ? ln0 + r : min(ln0 + r, g.N - 1);
         srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + (j ^ fh2_swz(r)) * 16;
     }
+    int c_tap = 0, c_ci = 0;                                          // AMODE 1: (tap, first channel) of the next stage to issue (stages are issued in order)
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
         const size_t koff = (size_t)kt * 128;
+        long delta = 0;
+        if (AMODE == 1) {
+            const int dy = c_tap / 3, dx = c_tap - 3 * dy;
+            delta = ((long)(dy - 1) * g.cW + (dx - 1)) * ((long)g.cCin * 4) + (long)c_ci * 4;
+        }
 #pragma unroll
-        for (int i = 0; i < LA; i++) __builtin_amdgcn_global_load_lds((fh2_gptr)(srcA[i] + koff), (fh2_lptr)(base + NT * 16 * i), 16, 0, 0);
+        for (int i = 0; i < LA; i++) {
+            const char* src = AMODE == 0 ? srcA[i] + koff : ((tapsA[i] >> c_tap) & 1 ? srcA[i] + delta : reinterpret_cast<const char*>(g_fh2_zero));
+            __builtin_amdgcn_global_load_lds((fh2_gptr)src, (fh2_lptr)(base + NT * 16 * i), 16, 0, 0);
+        }
+        if (AMODE == 1) {
+            c_ci += 32;
+            if (c_ci >= g.cCin) { c_ci = 0; c_tap++; }
+        }
 #pragma unroll
         for (int i = 0; i < LB; i++)
             __builtin_amdgcn_global_load_lds((fh2_gptr)(srcB[i] + koff), (fh2_lptr)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
@@ -189,101 +225,69 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
         offA[p] = ((wm * WTM + frow) * U + c) * 16;
         offB[p] = SA * 16 + ((wn * WTN + frow) * U + c) * 16;
     }
-    if constexpr (PIPE) {
-        // Software-pipelined form: the fragments of k-step kt+1 are read from LDS WHILE the matrix cores work on k-step kt.  The A
-        // fragments roll in place (row i's registers are reloaded right after row i's MFMAs are issued), the B fragments are double
-        // buffered by k-step parity.  Ring: on entry to k-step kt stage kt is in registers, stage kt+1 is waited for (own DMAs, then
-        // the barrier covers everybody's), its buffer is read during the step, and the DMA of stage kt+NS goes into stage kt's
-        // buffer (every wave's reads of it completed before the barrier): NS-1 stages stay in flight behind the one being read.
-        const int npro = nk < NS ? nk : NS;
-        for (int t = 0; t < npro; t++) issue(t, t);
-        fh2_wait_vmcnt_dyn((npro - 1) * LPS);
-        __builtin_amdgcn_s_barrier();
-        f16x8 af[TM][2], bfr[2][TN][2];
+    // Software-pipelined form: the fragments of k-step kt+1 are read from LDS WHILE the matrix cores work on k-step kt.  The A
+    // fragments roll in place (row i's registers are reloaded right after row i's MFMAs are issued), the B fragments are double
+    // buffered by k-step parity.  Ring: on entry to k-step kt stage kt is in registers, stage kt+1 is waited for (own DMAs, then
+    // the barrier covers everybody's), its buffer is read during the step, and the DMA of stage kt+NS goes into stage kt's
+    // buffer (every wave's reads of it completed before the barrier): NS-1 stages stay in flight behind the one being read.
+    const int npro = nk < NS ? nk : NS;
+    for (int t = 0; t < npro; t++) issue(t, t);
+    fh2_wait_vmcnt_dyn((npro - 1) * LPS);
+    __builtin_amdgcn_s_barrier();
+    f16x8 af[TM][2], bfr[2][TN][2];
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(smem + offA[p] + i * 16 * U * 16);
+        for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(smem + offA[p] + i * 16 * U * 16);
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+    for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) bfr[0][j][p] = *reinterpret_cast<const f16x8*>(smem + offB[p] + j * 16 * U * 16);
-        int nbuf = 1 % NS;                                         // ring slot of stage kt + 1
-        auto kstep = [&](int kt, f16x8 (&bc)[TN][2], f16x8 (&bn)[TN][2], auto has_next) {
-            constexpr bool NEXT = decltype(has_next)::value;
-            const char* sb = smem + nbuf * STAGE;
+        for (int p = 0; p < 2; p++) bfr[0][j][p] = *reinterpret_cast<const f16x8*>(smem + offB[p] + j * 16 * U * 16);
+    int nbuf = 1 % NS;                                         // ring slot of stage kt + 1
+    auto kstep = [&](int kt, f16x8 (&bc)[TN][2], f16x8 (&bn)[TN][2], auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        const char* sb = smem + nbuf * STAGE;
+        if constexpr (NEXT) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): stage kt is in registers: its buffer may be overwritten after the barrier
+            if (kt + NS <= nk) fh2_wait_vmcnt<(NS - 2) * LPS>();
+            else fh2_wait_vmcnt_dyn((nk - kt - 2) * LPS);
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS < nk && LAB != 3 && LAB != 4 && (LAB != 5 || (wave >> 2) == 0)) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) bn[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) {                     // smallest terms first
+                if constexpr (LAB == 2 || LAB == 4) { acc[i][j][0] += (float)af[i][1][0] + (float)bc[j][1][0] + (float)af[i][0][1] + (float)bc[j][0][1]; continue; }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
+            }
             if constexpr (NEXT) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): stage kt is in registers: its buffer may be overwritten after the barrier
-                if (kt + NS <= nk) fh2_wait_vmcnt<(NS - 2) * LPS>();
-                else fh2_wait_vmcnt_dyn((nk - kt - 2) * LPS);
-                __builtin_amdgcn_s_barrier();
-                if (kt + NS < nk && LAB != 3 && LAB != 4 && (LAB != 5 || (wave >> 2) == 0)) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (LAB == 5 && i + 1 < 4 && (wave >> 2) == i + 1 && kt + NS < nk) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int p = 0; p < 2; p++) bn[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
+                for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(sb + offA[p] + i * 16 * U * 16);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-#pragma unroll
-                for (int j = 0; j < TN; j++) {                     // smallest terms first
-                    if constexpr (LAB == 2 || LAB == 4) { acc[i][j][0] += (float)af[i][1][0] + (float)bc[j][1][0] + (float)af[i][0][1] + (float)bc[j][0][1]; continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
-                }
-                if constexpr (NEXT) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (LAB == 5 && i + 1 < 4 && (wave >> 2) == i + 1 && kt + NS < nk) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
-#pragma unroll
-                    for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(sb + offA[p] + i * 16 * U * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
-        };
-        int kt = 0;
-        for (; kt + 2 < nk; kt += 2) {
-            kstep(kt, bfr[0], bfr[1], std::true_type{});
-            kstep(kt + 1, bfr[1], bfr[0], std::true_type{});
         }
-        if (kt + 1 < nk) {
-            kstep(kt, bfr[0], bfr[1], std::true_type{});
-            kstep(kt + 1, bfr[1], bfr[0], std::false_type{});
-        } else {
-            kstep(kt, bfr[0], bfr[1], std::false_type{});
-        }
-    } else {
-    auto acquire = [&](int kt) {
-        const int rem = nk - 1 - kt, fly = rem < NS - 2 ? rem : NS - 2;
-        fh2_wait_vmcnt_dyn(fly * LPS);
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     };
-    for (int t = 0; t < NS - 1 && t < nk; t++) issue(t, t);
-    for (int kt = 0; kt < nk; kt++) {
-        acquire(kt);
-        const char* sb = smem + (kt % NS) * STAGE;
-        f16x8 af[TM][2], bf[TN][2];
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(sb + offA[p] + i * 16 * U * 16);
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int p = 0; p < 2; p++) bf[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            }
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        kstep(kt, bfr[0], bfr[1], std::true_type{});
+        kstep(kt + 1, bfr[1], bfr[0], std::true_type{});
     }
+    if (kt + 1 < nk) {
+        kstep(kt, bfr[0], bfr[1], std::true_type{});
+        kstep(kt + 1, bfr[1], bfr[0], std::false_type{});
+    } else {
+        kstep(kt, bfr[0], bfr[1], std::false_type{});
     }
     // undo the weight scale (an exact power of two), then the shared epilogues
     const float inv = fa.inv_wscale[grp];
@@ -355,9 +359,9 @@ static int choose_fh2_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL, bool PIPE, int LAB = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, int LAB = 0, int AMODE = 0>
 static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
-    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, PIPE, LAB>;
+    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, LAB, AMODE>;
     constexpr int ring = NS * (BM + BN) * 128, epi = WM * WN * epi_lds_wave_bytes(BM / WM), lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
@@ -369,39 +373,42 @@ static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
     return A3R_OK;
 }
 
+template <int AMODE>
 static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     GemmArgs& g = fa.g;
     g.direct_epilogue = 0;
     if (const char* l = getenv("A3R_FH2_LAB")) fa.lab = atoi(l);
-    const int t = choose_fh2_tile(g.M, g.N, g.groups);
+    int t = choose_fh2_tile(g.M, g.N, g.groups);
+    if (AMODE == 1 && t != 0) t = 2;                       // the implicit conv is built for tiles 0 and 2
     const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
     g.tiles_per_group = g.tiles_m * g.tiles_n;
-    const bool full = g.M % bm == 0 && g.N % bn == 0 && !getenv("A3R_FH2_NOFULL");
+    const bool full = g.M % bm == 0 && g.N % bn == 0;
     const double mn = (double)g.M * g.N;
-    const double c_bytes = mn * ((g.epi.out_fh2 ? 4.0 : g.epi.out_bf3 ? 6.0 : 4.0) + (g.epi.aux_bf3 ? 6.0 : 0.0) +
-                                 (g.epi.epi == A3R_EPI_RESID ? 4.0 : g.epi.epi == A3R_EPI_RESID2 ? 8.0 : 0.0));
-    ProfScope prof(PK_LINEAR_FH2, 2.0 * g.M * g.N * g.K * g.groups, st, g.groups * (4.0 * g.M * g.K + 4.0 * g.N * g.K + c_bytes));
-    static const bool pipe = !(getenv("A3R_FH2_PIPE") && atoi(getenv("A3R_FH2_PIPE")) == 0);
+    const double c_bytes = mn * (4.0 + (g.epi.aux_fh2 ? 4.0 : 0.0) + (g.epi.epi == A3R_EPI_RESID ? 4.0 : g.epi.epi == A3R_EPI_RESID2 ? 8.0 : 0.0));
+    // algorithmic bytes: operands once (the conv's input map once, not once per tap), weights once, outputs once
+    const double a_bytes = AMODE == 1 ? 4.0 * (g.M / (g.cHo * g.cWo)) * g.cH * g.cW * g.cCin : 4.0 * g.M * g.K;
+    ProfScope prof(AMODE == 1 ? PK_CONV_FH2 : PK_LINEAR_FH2, 2.0 * g.M * g.N * g.K * g.groups, st, g.groups * (a_bytes + 4.0 * g.N * g.K + c_bytes));
     if (t == 0) {
 #ifdef A3R_FH2_LABS                                        // component-isolation experiments (wrong results by design): make CXXFLAGS+=-DA3R_FH2_LABS
-        if (full && pipe && fa.lab >= 2) {
+        if (AMODE == 0 && full && fa.lab >= 2) {
             switch (fa.lab) {
-                case 2: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 2>(fa, st);
-                case 3: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 3>(fa, st);
-                case 4: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 4>(fa, st);
-                case 5: return launch_fh2_variant<256, 128, 4, 4, 3, true, true, 5>(fa, st);
+                case 2: return launch_fh2_variant<256, 128, 4, 4, 3, true, 2>(fa, st);
+                case 3: return launch_fh2_variant<256, 128, 4, 4, 3, true, 3>(fa, st);
+                case 4: return launch_fh2_variant<256, 128, 4, 4, 3, true, 4>(fa, st);
+                case 5: return launch_fh2_variant<256, 128, 4, 4, 3, true, 5>(fa, st);
             }
         }
 #endif
-        if (pipe) return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, true>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, true>(fa, st);
-        return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, false>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, false>(fa, st);
+        return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, 0, AMODE>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, 0, AMODE>(fa, st);
     }
-    if (t == 3) return full ? launch_fh2_variant<256, 128, 4, 2, 3, true, true>(fa, st) : launch_fh2_variant<256, 128, 4, 2, 3, false, true>(fa, st);
-    if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, true>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, true>(fa, st);
-    if (pipe) return full ? launch_fh2_variant<128, 64, 4, 2, 3, true, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false, true>(fa, st);
-    return full ? launch_fh2_variant<128, 64, 4, 2, 3, true, false>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false, false>(fa, st);
+    if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, 0, AMODE>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, 0, AMODE>(fa, st);
+    if constexpr (AMODE == 0) {
+        if (t == 3) return full ? launch_fh2_variant<256, 128, 4, 2, 3, true>(fa, st) : launch_fh2_variant<256, 128, 4, 2, 3, false>(fa, st);
+        return full ? launch_fh2_variant<128, 64, 4, 2, 3, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false>(fa, st);
+    }
+    return A3R_EINVAL;
 }
 
 }  // namespace a3r
@@ -455,6 +462,10 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
     if (epi) g.epi = *epi;
     A3R_CHECK_ARG(!g.epi.relu_a && !g.epi.x_pair && !g.epi.out_pair, "a3r_linear_fh2: relu_a / x_pair / out_pair do not apply to fh2 operands");
     A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF, "a3r_linear_fh2: PIXSHUF is not available");
+    if (g.epi.aux_fh2)
+        A3R_CHECK_ARG(!g.epi.out_fh2 && !g.epi.out_bf3 && N % 8 == 0 && ldc == N && g.epi.epi != A3R_EPI_PIXSHUF &&
+                          (reinterpret_cast<uintptr_t>(g.epi.aux_fh2) & 15) == 0,
+                      "a3r_linear_fh2: aux_fh2 needs an fp32 y with ldc == N, N %% 8 == 0 and a 16-byte aligned buffer");
     if (g.epi.out_fh2) {
         A3R_CHECK_ARG(!g.epi.out_bf3 && !g.epi.aux_bf3, "a3r_linear_fh2: out_fh2 excludes out_bf3 / aux_bf3");
         A3R_CHECK_ARG(N % 32 == 0 && ldc == N && (g.epi.epi == A3R_EPI_NONE || g.epi.epi == A3R_EPI_GELU || g.epi.epi == A3R_EPI_RELU ||
@@ -472,11 +483,42 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
     g.lda = K; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     A3R_CHECK_ARG(ldc >= N, "a3r_linear_fh2: ldc (%d) < N (%d)", ldc, N);
     if (g.epi.out_bf3) A3R_CHECK_ARG(ldc == N, "a3r_linear_fh2: out_bf3 needs ldc == N");
-    return launch_fh2(fa, as_stream(stream));
+    return launch_fh2<0>(fa, as_stream(stream));
 }
 
 extern "C" int a3r_linear_fh2(const void* x2, const void* w2, float w_scale, float* y, int ldc, int M, int N, int K,
                               const a3r_epilogue* epi, void* stream) {
     a3r_group_ptrs_fh2 p = {x2, w2, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr, w_scale};
     return a3r_linear_fh2_grouped(&p, 1, ldc, M, N, K, epi, stream);
+}
+
+extern "C" int a3r_conv3x3_fh2(const void* x2, const void* wp2, float w_scale, float* y, int B, int H, int W, int Cin, int Cout, int stride,
+                               const a3r_epilogue* epi, void* stream) {
+    A3R_CHECK_ARG(x2 && wp2 && y, "a3r_conv3x3_fh2: null pointer");
+    A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "a3r_conv3x3_fh2: bad shape");
+    A3R_CHECK_ARG(stride == 1 || stride == 2, "a3r_conv3x3_fh2: stride must be 1 or 2");
+    A3R_CHECK_ARG(Cin % 32 == 0, "a3r_conv3x3_fh2: Cin (%d) must be a multiple of 32", Cin);
+    A3R_CHECK_ARG(w_scale > 0.f, "a3r_conv3x3_fh2: w_scale must be positive");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long M = (long)B * Ho * Wo;
+    A3R_CHECK_ARG(M < (1L << 31) && (long)B * H * W * Cin * 4 < (1L << 46), "a3r_conv3x3_fh2: map too large");
+    if (int rc = check_epilogue(epi, (int)M, Cout, "a3r_conv3x3_fh2", true)) return rc;
+    Fh2Args fa = {};
+    GemmArgs& g = fa.g;
+    if (epi) g.epi = *epi;
+    A3R_CHECK_ARG(!g.epi.relu_a && !g.epi.x_pair && !g.epi.out_pair && !g.epi.out_bf3 && !g.epi.aux_bf3,
+                  "a3r_conv3x3_fh2: relu_a / row-pair / bf3 outputs do not apply (the producer writes the pre-activated fh2 input: aux_fh2 + aux_relu)");
+    A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF && g.epi.epi != A3R_EPI_ROPE, "a3r_conv3x3_fh2: PIXSHUF / ROPE are not available");
+    if (g.epi.out_fh2)
+        A3R_CHECK_ARG(!g.epi.aux_fh2 && Cout % 32 == 0 && (g.epi.epi == A3R_EPI_NONE || g.epi.epi == A3R_EPI_GELU || g.epi.epi == A3R_EPI_RELU),
+                      "a3r_conv3x3_fh2: out_fh2 needs Cout %% 32 == 0, a NONE / GELU / RELU epilogue and no aux_fh2");
+    if (g.epi.aux_fh2)
+        A3R_CHECK_ARG(Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(g.epi.aux_fh2) & 15) == 0, "a3r_conv3x3_fh2: aux_fh2 needs Cout %% 8 == 0 and a 16-byte aligned buffer");
+    g.grp[0] = {static_cast<const float*>(x2), static_cast<const float*>(wp2), y, g.epi.bias, g.epi.resid, g.epi.resid2};
+    if (int rc = check_group(g.grp[0], g.epi.epi, "a3r_conv3x3_fh2")) return rc;
+    fa.inv_wscale[0] = 1.f / w_scale;
+    g.groups = 1;
+    g.M = (int)M; g.N = Cout; g.K = 9 * Cin; g.lda = g.K; g.ldc = Cout;
+    g.cH = H; g.cW = W; g.cCin = Cin; g.cHo = Ho; g.cWo = Wo; g.cStride = stride;
+    return launch_fh2<1>(fa, as_stream(stream));
 }

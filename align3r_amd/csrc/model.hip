@@ -67,6 +67,7 @@ struct a3r_model_s {
     // transformer nn.Linear weights in fh2 form (two fp16 planes, gemm_fh2.hip) unless A3R_GEMM names another mode:
     // fp32 pointer -> (fh2 twin in `packed`, the power-of-two scale it was stored with)
     bool use_fh2 = true;
+    bool conv_fh2 = true;     // fh2 mode: the DPT maps / 3x3 convs on the fh2 kernel too (A3R_CONV=bf3 keeps them on the three-plane bf16 kernel)
     std::map<const float*, std::pair<const void*, float>> w2;
     static constexpr int MAX_POS = 256;
 };
@@ -94,6 +95,8 @@ extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
         m->products = mode == "bf16" ? 1 : mode == "bf3x3" ? 3 : 6;
         m->use_fh2 = !(mode == "f32" || mode == "bf3" || mode == "bf3x3" || mode == "bf16");
     }
+    if (const char* e = getenv("A3R_CONV")) m->conv_fh2 = std::string(e) != "bf3";
+    m->conv_fh2 = m->conv_fh2 && m->use_bf3 && m->use_fh2;
     // sized here so that the host-side sizing pass (a3r_model_workspace_bytes) works before finalize
     m->enc.assign(cfg->enc_depth, BlockW());
     m->pc.assign(n_pc_blocks(*cfg), BlockW());
@@ -190,10 +193,14 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
         std::vector<PackItem> convs;
         for (const PackItem& it : v)
             if (it.kind == 0) convs.push_back(it);
-        for (const PackItem& it : convs) twin(it.name, it.a, 9 * it.b);
+        auto twin_conv = [&](const std::string& n, int N, int K) {
+            if (m->conv_fh2) twin_lin(n, N, K);
+            else twin(n, N, K);
+        };
+        for (const PackItem& it : convs) twin_conv(it.name, it.a, 9 * it.b);
         for (int h = 1; h <= 2; h++)
             for (int r = 1; r <= 4; r++)
-                twin("downstream_head" + std::to_string(h) + ".dpt.scratch.refinenet" + std::to_string(r) + ".out_conv.weight", F, F);
+                twin_conv("downstream_head" + std::to_string(h) + ".dpt.scratch.refinenet" + std::to_string(r) + ".out_conv.weight", F, F);
     }
     *total = off;
     return v;
@@ -423,8 +430,18 @@ struct Plan {
     // ---- attention operands (q / k / v written by the RoPE projections): fh2 in fh2 mode, bf3 in the bf3 modes
     float* att_alloc(size_t rows, int K) { return ar.alloc(bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
     template <class T> T* att_at(T* base, size_t rows, int K) const { return base + (bf3() && !fh2() ? rows * K * 3 / 2 : rows * K); }
-    // maps that are only ever conv inputs (DPT): bf3 form in every bf3 / fh2 mode
-    float* map_alloc(size_t rows, int K) { return ar.alloc(bf3() ? rows * K * 3 / 2 : rows * K); }
+    bool cf2() const { return m->conv_fh2; }                  // DPT maps in fh2 form (else bf3 form in every bf3 / fh2 mode)
+    // maps that are only ever conv inputs (DPT)
+    float* map_alloc(size_t rows, int K) { return ar.alloc(bf3() && !cf2() ? rows * K * 3 / 2 : rows * K); }
+    // a "bf3 output" request of the DPT plan means "the conv-input form": fh2 when the convs run on the fh2 kernel
+    a3r_epilogue map_epi(const a3r_epilogue& e0) const {
+        a3r_epilogue e = e0;
+        if (cf2()) {
+            if (e.out_bf3) { e.out_bf3 = 0; e.out_fh2 = 1; }
+            if (e.aux_bf3) { e.aux_fh2 = e.aux_bf3; e.aux_bf3 = nullptr; }
+        }
+        return e;
+    }
     // column `col` (a multiple of 8) of a gin row
     const float* gin_col(const float* base, int col) const {
         return bf3() && !fh2() ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)col * 6) : base + col;
@@ -461,9 +478,10 @@ struct Plan {
                 bool plain_x = false) {
         if (skip()) return;
         traced("linear", M, N, K);
-        if (fh2() && !plain_x) {
+        if (fh2() && (!plain_x || cf2())) {
             const auto* w2 = twin2(w);
-            if (w2) rc = a3r_linear_fh2(xg, w2->first, w2->second, y, ldc, M, N, K, &e0, stream);
+            const a3r_epilogue e = plain_x ? map_epi(e0) : e0;
+            if (w2) rc = a3r_linear_fh2(xg, w2->first, w2->second, y, ldc, M, N, K, &e, stream);
         } else if (bf3()) {
             const void* w3 = twin(w);
             a3r_epilogue e = e0;
@@ -503,22 +521,28 @@ struct Plan {
         }
     }
     // ---- bf3-mode helpers of the DPT heads
-    float* alloc3(size_t rows, int K) { return ar.alloc(rows * K * 3 / 2); }      // a bf3 [rows, K] buffer
+    float* alloc3(size_t rows, int K) { return ar.alloc(cf2() ? rows * K : rows * K * 3 / 2); }      // a conv-input [rows, K] buffer (bf3 or fh2 form)
     void split(const float* x, float* y3, long M, int K) {
         if (skip()) return;
-        traced("split_bf3", (int)M, K);
-        rc = a3r_split_bf3(x, K, y3, M, K, stream);
+        traced("split_map", (int)M, K);
+        rc = cf2() ? a3r_split_fh2(x, K, y3, M, K, 1.f, stream) : a3r_split_bf3(x, K, y3, M, K, stream);
     }
-    void conv3(const float* x3, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
+    void conv3(const float* x3, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e0) {
         if (skip()) return;
-        traced("conv3x3_bf3", H, W, Cin);
+        traced("conv3x3_map", H, W, Cin);
+        if (cf2()) {
+            const auto* w2 = twin2(wp);
+            const a3r_epilogue e = map_epi(e0);
+            if (w2) rc = a3r_conv3x3_fh2(x3, w2->first, w2->second, y, B, H, W, Cin, Cout, stride, &e, stream);
+            return;
+        }
         const void* w3 = twin(wp);
-        if (w3) rc = a3r_conv3x3_bf3(x3, w3, y, B, H, W, Cin, Cout, stride, &e, stream);
+        if (w3) rc = a3r_conv3x3_bf3(x3, w3, y, B, H, W, Cin, Cout, stride, &e0, stream);
     }
     void up3(const float* x, float* y3, int B, int H, int W, int C, int Hc, int Wc) {
         if (skip()) return;
-        traced("upsample2x_bf3", H, W, C);
-        rc = a3r_upsample2x_bf3(x, y3, B, H, W, C, Hc, Wc, stream);
+        traced("upsample2x_map", H, W, C);
+        rc = cf2() ? a3r_upsample2x_fh2(x, y3, B, H, W, C, Hc, Wc, stream) : a3r_upsample2x_bf3(x, y3, B, H, W, C, Hc, Wc, stream);
     }
     // LayerNorm whose output feeds a GEMM (written directly in bf3 form in bf3 mode)
     void ln(const float* x, const float* w, const float* b, float* yg, int M, int D) {

@@ -66,9 +66,10 @@ def layernorm(x, w, b, eps=1e-6, out=None):
 
 
 def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
-                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False):
+                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False, aux_fh2=None):
     e = Epilogue()
     e.out_fh2 = int(out_fh2)
+    e.aux_fh2 = None if aux_fh2 is None else aux_fh2.data_ptr()
     e.out_bf3 = int(out_bf3)
     e.out_pair = int(out_pair)
     e.aux_bf3 = None if aux_bf3 is None else aux_bf3.data_ptr()
@@ -410,6 +411,34 @@ def patchify(img, channels_last=False):
     cols = torch.empty((B * (H // 16) * (W // 16), Cc * 256), device=img.device, dtype=torch.float32)
     check(_lib.load().a3r_patchify(ptr(img), ptr(cols), B, Cc, H, W, *strides, stream_ptr()), "patchify")
     return cols
+
+
+def conv3x3_fh2(x2: Fh2, wp2: Fh2, shape, bias=None, stride=1, epi=_lib.EPI_NONE, **kw):
+    """3x3 conv (padding 1) on the fh2 kernel: x2 = fh2 of the channels-last map `shape` = (B, H, W, Cin), wp2 = fh2 of the packed
+    weights [Cout, 9 Cin] (split_fh2_w).  Returns fp32 [B, Ho, Wo, Cout] (or an Fh2 with out_fh2=True); aux_fh2=Fh2 also receives
+    the fh2 form of the result (through a ReLU with aux_relu=True)."""
+    B, H, W, Cin = shape
+    Cout = wp2.rows
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    e = make_epilogue(epi, bias, **kw)
+    dev = x2.data.device
+    if e.out_fh2:
+        out = Fh2(torch.zeros(B * Ho * Wo * Cout * 4, device=dev, dtype=torch.uint8), B * Ho * Wo, Cout)
+    else:
+        out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float32)
+    check(_lib.load().a3r_conv3x3_fh2(x2.data_ptr(), wp2.data_ptr(), wp2.scale, out.data_ptr(), B, H, W, Cin, Cout, stride, C.byref(e),
+                                      stream_ptr()), "conv3x3_fh2")
+    return out
+
+
+def upsample2x_fh2(x, crop=None) -> Fh2:
+    """upsample2x written in fh2 form (rows = output pixels, K = C)."""
+    _req(x, "x")
+    B, H, W, Cc = x.shape
+    Hc, Wc = crop if crop else (2 * H, 2 * W)
+    out = Fh2(torch.zeros(B * Hc * Wc * Cc * 4, device=x.device, dtype=torch.uint8), B * Hc * Wc, Cc)
+    check(_lib.load().a3r_upsample2x_fh2(ptr(x), out.data_ptr(), B, H, W, Cc, Hc, Wc, stream_ptr()), "upsample2x_fh2")
+    return out
 
 
 def upsample2x(x, crop=None):

@@ -113,6 +113,9 @@ typedef struct {
     /* a3r_linear_fh2 only: write y in fh2 form ([M][N/8][2][8] fp16, N % 32 == 0, ldc = N) instead of fp32, for outputs that only
      * feed the next a3r_linear_fh2 (Mlp: fc1 + GELU -> fc2, blocks.py:73-77).  NONE / GELU / RELU. */
     int out_fh2;
+    /* fh2 kernels only: ALSO write the result (after bias / activation / residuals; through a ReLU if aux_relu) in fh2 form
+     * [M][N/8][2][8] to aux_fh2 -- as aux_bf3, for the DPT convolutions on the fh2 kernel (y, resid, resid2 16-byte aligned). */
+    void* aux_fh2;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
@@ -208,6 +211,12 @@ int a3r_linear_fh2(const void* x2, const void* w2, float w_scale, float* y, int 
 int a3r_conv3x3_bf3(const void* x3, const void* wp3, float* y, int B, int H, int W, int Cin, int Cout, int stride,
                     const a3r_epilogue* epi, void* stream);
 
+/* The same on the fh2 kernel: x2 = fh2 form of the channels-last map (scale 1), wp2 = fh2 form of the packed weights [Cout, 9 Cin]
+ * (a3r_pack_conv3x3 then a3r_split_fh2 with the power-of-two w_scale of a3r_fh2_weight_scale); Cin % 32 == 0.  y fp32
+ * (optionally also aux_fh2) or fh2 (out_fh2, Cout % 32 == 0).  Same call sites as a3r_conv3x3 (dpt_block.py:120-142, 186-218, 323-330). */
+int a3r_conv3x3_fh2(const void* x2, const void* wp2, float w_scale, float* y, int B, int H, int W, int Cin, int Cout, int stride,
+                    const a3r_epilogue* epi, void* stream);
+
 /* nn.Conv2d(k=3, padding=1, stride in {1,2}) on channels-last x [B, H, W, Cin] with PACKED weights
  * wp [Cout, 3, 3, Cin] (a3r_pack_conv3x3 from the checkpoint layout [Cout, Cin, 3, 3]); Cin % 32 == 0.
  * y [B, Ho, Wo, Cout].  Implicit GEMM on the same MFMA core.  (dpt_block.py:33-68,93-111,323-329,402-405) */
@@ -261,6 +270,8 @@ int a3r_umeyama_moments(const float* x, const float* y, const float* w, const lo
 int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 /* the same, written in bf3 form ([B Hc Wc][C/8][3][8] bf16, C % 8 == 0): input of the next conv on the bf3 kernel */
 int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W, int C, int Hc, int Wc, void* stream);
+/* the same, written in fh2 form ([B Hc Wc][C/8][2][8] fp16, C % 8 == 0): input of the next conv on the fh2 kernel */
+int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 
 /* last 1x1 conv (128 -> 4) + postprocess (dpt_block.py:329, postprocess.py:10-58):
  * x [P, C] -> pts3d [P, 3] = xyz/max(|xyz|,1e-8)*expm1(|xyz|), conf [P] = 1 + exp(c). */

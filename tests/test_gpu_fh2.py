@@ -133,3 +133,42 @@ def test_linear_fh2_rope_to_fh2(ops):
             assert float((got - want).abs().max() / want.abs().max()) < 1e-6, (M, N, K, rope_cols)
             ref = ops.linear(x, w, b, epi=_lib.EPI_ROPE, rope=(rope_cols, 25, 5, cos, sin)).double()
             assert float((got - ref).abs().max() / ref.abs().max()) < 3e-6
+
+
+@pytest.mark.parametrize("tile", ["0", "2"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 12, 16, 64, 64, 1), (1, 24, 32, 96, 256, 1), (2, 9, 7, 32, 128, 2),
+                                                    (1, 5, 5, 256, 64, 1), (1, 48, 64, 128, 128, 1)])
+def test_conv3x3_fh2_vs_float64(ops, monkeypatch, tile, B, H, W, Cin, Cout, stride):
+    """DPT-head 3x3 convs (dpt_block.py:33-142,323-329) as an implicit GEMM on the fh2 kernel, incl. padding and stride 2: error
+    against float64 not larger than the exact-fp32 MFMA conv's; the fused outputs are exactly the splits of the fp32 results."""
+    monkeypatch.setenv("A3R_FH2_TILE", tile)
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=3)
+    wp = ops.pack_conv3x3(w)
+    x2 = ops.split_fh2(x)
+    wp2 = ops.split_fh2_w(wp.reshape(Cout, 9 * Cin))
+    xd, wd = x.double().permute(0, 3, 1, 2), w.double()
+    ref = torch.nn.functional.conv2d(xd, wd, b.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    den = torch.nn.functional.conv2d(xd.abs(), wd.abs(), b.double().abs(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    y = ops.conv3x3_fh2(x2, wp2, (B, H, W, Cin), b, stride=stride)
+    y32 = ops.conv3x3(x, wp, b, stride=stride)
+    e2 = float(((y.double() - ref).abs() / den).max())
+    e32 = float(((y32.double() - ref).abs() / den).max())
+    assert e2 < 3e-7 and e2 <= 1.5 * e32 + 1e-8, (e2, e32)
+    # ResidualConvUnit pieces: relu epilogue straight to fh2; residual epilogue + pre-activated fh2 side output
+    y2 = ops.conv3x3_fh2(x2, wp2, (B, H, W, Cin), b, stride=stride, epi=_lib.EPI_RELU, out_fh2=True)
+    assert torch.equal(y2.data, ops.split_fh2(torch.relu(y)).data)
+    r = rnd(*y.shape, seed=5)
+    aux = ops.Fh2(torch.zeros(y.numel() * 4, dtype=torch.uint8, device="cuda"), y.numel() // Cout, Cout)
+    z = ops.conv3x3_fh2(x2, wp2, (B, H, W, Cin), b, stride=stride, epi=_lib.EPI_RESID, resid=r, aux_fh2=aux, aux_relu=True)
+    assert float((z - (y + r)).abs().max()) <= 1e-6 * float(z.abs().max())
+    assert torch.equal(aux.data, ops.split_fh2(torch.relu(z)).data)
+    aux.data.zero_()
+    z2 = ops.conv3x3_fh2(x2, wp2, (B, H, W, Cin), b, stride=stride, epi=_lib.EPI_RESID2, resid=r, resid2=y, aux_fh2=aux)
+    assert torch.equal(aux.data, ops.split_fh2(z2).data)
+
+
+def test_upsample2x_fh2(ops):
+    x = rnd(2, 7, 9, 64, seed=1)
+    assert torch.equal(ops.upsample2x_fh2(x, crop=(13, 18)).data, ops.split_fh2(ops.upsample2x(x, crop=(13, 18))).data)
