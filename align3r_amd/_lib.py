@@ -104,6 +104,11 @@ SIGNATURES = {
     "a3r_patchify": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, c_void]),
     "a3r_upsample2x": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_upsample2x_bf3": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_umeyama_solve": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void]),
+    "a3r_pnp_desc_bytes": (C.c_size_t, []),
+    "a3r_pnp_chunks": (C.c_int, [C.c_int]),
+    "a3r_pnp_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "a3r_pnp_solve": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
     "a3r_upsample2x_fh2": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_conv3x3_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_head_final": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_long, C.c_int, c_void]),

@@ -2,8 +2,9 @@
 
 PARITY UNPINNED: the reference builds this step on third-party solvers that are not available here and whose
 results it never pins -- roma.rigid_points_registration (SVD Procrustes, :415-418) and cv2.solvePnPRansac with
-SQPNP (:442-482, stochastic).  This module restates the published algorithms (weighted Umeyama; a linear PnP with
-known intrinsics followed by an orthogonal Procrustes step and two IRLS rounds instead of RANSAC) and is validated
+SQPNP (:442-482, stochastic).  This module restates the published algorithms (weighted Umeyama; PnP with known
+intrinsics as a closed-form start + robust Gauss-Newton on the reprojection error instead of RANSAC; both solved on the device by
+the kernels of csrc/init.hip -- no LAPACK, no host round trip per problem) and is validated
 by what it is for: the alignment loss after initialisation and the recovered geometry on synthetic scenes
 (tests/test_gpu_api.py).  The order of operations, the edge scores (commons.py:20-25), the spanning tree
 (scipy.sparse.csgraph), the Weiszfeld focal (post_process.py:36-60) and what gets written into the optimiser
@@ -28,7 +29,7 @@ def _solve_from_moments(m):
     xm, ym = m[:, 1:4] / w0, m[:, 4:7] / w0
     var_x = m[:, 7] / w0[:, 0] - xm.square().sum(-1)
     cov = m[:, 8:17].reshape(-1, 3, 3) / w0[:, :, None] - ym[:, :, None] * xm[:, None, :]
-    U, S, Vt = torch.linalg.svd(cov)
+    U, S, Vt = (torch.from_numpy(a) for a in np.linalg.svd(cov.numpy()))      # host path: a handful of camera centres
     d = torch.ones_like(S)
     d[:, 2] = torch.sign(torch.det(U @ Vt))
     R = (U * d[:, None, :]) @ Vt
@@ -37,25 +38,33 @@ def _solve_from_moments(m):
     return [(float(s[k]), R[k].float(), T[k].float()) for k in range(len(m))]
 
 
-def umeyama_moments(x, y, w, x_off, y_off, w_off, P):
-    """a3r_umeyama_moments over B problems on the device: x, y, w flat float32 device tensors, *_off int64 element offsets [B]
-    (device).  Returns the [B,17] float64 moments on the CPU (one synchronisation)."""
-    import ctypes as C
+def umeyama_solve(x, y, w, x_off, y_off, w_off, P):
+    """B weighted similarity registrations on the device, no synchronisation: a3r_umeyama_moments (17 float64 moments per problem,
+    fixed summation order) + a3r_umeyama_solve (closed form, 3x3 SVD by Jacobi).  x, y, w flat float32 device tensors, *_off int64
+    element offsets [B] (device).  Returns a float32 device tensor [B,13] = (s, R row-major, T)."""
     from ... import _lib
     from ..._lib import check, ptr, stream_ptr
     lib = _lib.load()
     B = int(x_off.numel())
     nch = int(lib.a3r_umeyama_chunks(P))
     partial = torch.empty((B, nch, 17), dtype=torch.float64, device=x.device)
+    out = torch.empty((B, 13), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         check(lib.a3r_umeyama_moments(ptr(x), ptr(y), ptr(w), ptr(x_off), ptr(y_off), ptr(w_off), B, P, ptr(partial), stream_ptr()),
               "a3r_umeyama_moments")
-    return partial.sum(1).cpu()
+        check(lib.a3r_umeyama_solve(ptr(partial), nch, B, ptr(out), stream_ptr()), "a3r_umeyama_solve")
+    return out
+
+
+def _unpack_sRT(sol):
+    """[13] -> (s 0-d, R [3,3], T [3]) views of one solution."""
+    return sol[0], sol[1:10].reshape(3, 3), sol[10:13]
 
 
 def rigid_points_registration(x, y, w):
-    """Weighted Umeyama: (s, R, T) minimising sum w |s R x + T - y|^2 for x, y [P,3], w [P] (device float32 tensors or CPU:
-    the tiny camera-centre problems of align_multiple_poses stay on the host)."""
+    """Weighted Umeyama: (s, R, T) minimising sum w |s R x + T - y|^2 for x, y [P,3], w [P].  Device float32 tensors: solved on
+    the device, the result stays there (s is a 0-d tensor).  CPU tensors (the tiny camera-centre problems of
+    align_multiple_poses): float64 closed form on the host, s a python float."""
     if not x.is_cuda:
         x, y, w = x.reshape(-1, 3).double(), y.reshape(-1, 3).double(), w.reshape(-1).double()
         m = torch.cat([w.sum()[None], (w[:, None] * x).sum(0), (w[:, None] * y).sum(0), (w * x.square().sum(-1)).sum()[None],
@@ -63,22 +72,57 @@ def rigid_points_registration(x, y, w):
         return _solve_from_moments(m)[0]
     x, y, w = x.reshape(-1, 3).float().contiguous(), y.reshape(-1, 3).float().contiguous(), w.reshape(-1).float().contiguous()
     zero = torch.zeros(1, dtype=torch.int64, device=x.device)
-    return _solve_from_moments(umeyama_moments(x, y, w, zero, zero, zero, x.shape[0]))[0]
+    return _unpack_sRT(umeyama_solve(x, y, w, zero, zero, zero, x.shape[0])[0])
 
 
 def rigid_points_registration_batched(X, Y, W, y_index):
-    """E registrations in one launch: X [E,P,3] against Y[y_index[e]] ([N,P,3]) with weights W [E,P] (contiguous float32, device)."""
+    """E registrations in two launches: X [E,P,3] against Y[y_index[e]] ([N,P,3]) with weights W [E,P] (contiguous float32, device).
+    Returns the device tensor [E,13] = (s, R row-major, T) per edge."""
     E, P, _ = X.shape
     dev = X.device
     ar = torch.arange(E, device=dev, dtype=torch.int64)
     yi = torch.as_tensor(y_index, device=dev, dtype=torch.int64)
-    return _solve_from_moments(umeyama_moments(X, Y, W, ar * (P * 3), yi * (P * 3), ar * P, P))
+    return umeyama_solve(X, Y, W, ar * (P * 3), yi * (P * 3), ar * P, P)
+
+
+def rotmat_to_unitquat_batched(R):
+    """[B,3,3] rotation matrices (device) -> [B,4] XYZW unit quaternions, the same largest-component branch selection as
+    commons.rotmat_to_unitquat, evaluated for all branches and selected per matrix (no synchronisation)."""
+    R = R.double()
+    m = lambda i, j: R[:, i, j]
+    tr = m(0, 0) + m(1, 1) + m(2, 2)
+    def branch(sq, q):
+        s = torch.sqrt(sq.clamp(min=1e-300)) * 2
+        return torch.stack([c(s) for c in q], -1)
+    b0 = branch(tr + 1.0, (lambda s: (m(2, 1) - m(1, 2)) / s, lambda s: (m(0, 2) - m(2, 0)) / s, lambda s: (m(1, 0) - m(0, 1)) / s,
+                           lambda s: 0.25 * s))
+    b1 = branch(1.0 + m(0, 0) - m(1, 1) - m(2, 2), (lambda s: 0.25 * s, lambda s: (m(0, 1) + m(1, 0)) / s,
+                                                    lambda s: (m(0, 2) + m(2, 0)) / s, lambda s: (m(2, 1) - m(1, 2)) / s))
+    b2 = branch(1.0 + m(1, 1) - m(0, 0) - m(2, 2), (lambda s: (m(0, 1) + m(1, 0)) / s, lambda s: 0.25 * s,
+                                                    lambda s: (m(1, 2) + m(2, 1)) / s, lambda s: (m(0, 2) - m(2, 0)) / s))
+    b3 = branch(1.0 + m(2, 2) - m(0, 0) - m(1, 1), (lambda s: (m(0, 2) + m(2, 0)) / s, lambda s: (m(1, 2) + m(2, 1)) / s,
+                                                    lambda s: 0.25 * s, lambda s: (m(1, 0) - m(0, 1)) / s))
+    c0 = (tr > 0)[:, None]
+    c1 = ((m(0, 0) > m(1, 1)) & (m(0, 0) > m(2, 2)))[:, None]
+    c2 = (m(1, 1) > m(2, 2))[:, None]
+    return torch.where(c0, b0, torch.where(c1, b1, torch.where(c2, b2, b3))).float()
+
+
+def inv_rigid(T):
+    """Inverse of [..., 4, 4] rigid transforms [R t; 0 1] in closed form: [R^T, -R^T t; 0 1] (no LAPACK call, no synchronisation)."""
+    Rt = T[..., :3, :3].transpose(-1, -2)
+    out = torch.zeros_like(T)
+    out[..., :3, :3] = Rt
+    out[..., :3, 3] = -(Rt @ T[..., :3, 3:4])[..., 0]
+    out[..., 3, 3] = 1
+    return out
 
 
 def sRT_to_4x4(scale, R, T, device):
+    """4x4 similarity from (s, R, T); s may be a python number or a 0-d tensor on `device` (no synchronisation either way)."""
     trf = torch.eye(4, device=device)
-    trf[:3, :3] = torch.as_tensor(R, device=device) * scale
-    trf[:3, 3] = torch.as_tensor(T, device=device).ravel()
+    trf[:3, :3] = torch.as_tensor(R, device=device, dtype=torch.float32) * scale
+    trf[:3, 3] = torch.as_tensor(T, device=device, dtype=torch.float32).ravel()
     return trf
 
 
@@ -122,73 +166,79 @@ def estimate_focal(pts3d_i):
     return estimate_focals(pts3d_i[None])[0]
 
 
-def linear_pnp(pts3d, focal, msk, pp=None, irls_rounds=2):
-    """Camera-to-world pose of an image whose pixels see the world points pts3d [H,W,3] (stands in for fast_pnp :442-482).
-    Direct linear transform on the calibrated rays, Procrustes projection of the 3x3 block, IRLS on the ray residual.
-    focal=None (an image that is never the first view of an edge, e.g. the last frame of a non-symmetrised graph): like
-    fast_pnp, try 21 focals in geomspace(S/2, 3S) and keep the one with most inliers (reprojection error < 5 px)."""
-    H, W, _ = pts3d.shape
-    if int(msk.sum()) < 6:
-        return None
-    if focal is None:
-        best = None
-        for f in np.geomspace(max(W, H) / 2, max(W, H) * 3, 21):
-            res = linear_pnp(pts3d, float(f), msk, pp=pp, irls_rounds=irls_rounds)
-            if res is None:
-                continue
-            c2w = res[1]
-            w2c = torch.linalg.inv(c2w.double())
-            cam = pts3d[msk].double() @ w2c[:3, :3].T + w2c[:3, 3]
-            ys, xs = torch.meshgrid(torch.arange(H, device=pts3d.device), torch.arange(W, device=pts3d.device), indexing='ij')
-            c = (W / 2, H / 2) if pp is None else pp
-            px = torch.stack((xs[msk] - c[0], ys[msk] - c[1]), -1).double()
-            err = (f * cam[:, :2] / cam[:, 2:3].clamp(min=1e-9) - px).norm(dim=-1)
-            score = int(((err < 5) & (cam[:, 2] > 0)).sum())
-            if best is None or score > best[0]:
-                best = (score, float(f), c2w)
-        return None if best is None or best[0] == 0 else (best[1], best[2])
-    dev = pts3d.device
-    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
-    pp = (W / 2, H / 2) if pp is None else pp
-    rays = torch.stack(((xs - pp[0]) / focal, (ys - pp[1]) / focal, torch.ones_like(xs, dtype=torch.float32)), -1)[msk].double()
-    X = pts3d[msk].double()
-    if len(X) > PNP_MAX_POINTS:          # a regular subsample is plenty for a 6-dof fit (the reference's RANSAC draws minimal sets)
-        step = -(-len(X) // PNP_MAX_POINTS)
-        rays, X = rays[::step], X[::step]
-    Xh = torch.cat((X, torch.ones_like(X[:, :1])), -1)                       # [n,4]
-    wgt = torch.ones(len(X), dtype=torch.float64, device=dev)
-    best = None
-    for _ in range(1 + irls_rounds):
-        # r x (P Xh) = 0  ->  two independent rows per point, unknown p = vec(P) (3x4, world -> camera)
-        rx, ry = rays[:, 0:1], rays[:, 1:2]
-        zero = torch.zeros_like(Xh)
-        A1 = torch.cat((Xh, zero, -rx * Xh), -1)
-        A2 = torch.cat((zero, Xh, -ry * Xh), -1)
-        A = torch.cat((A1 * wgt[:, None], A2 * wgt[:, None]), 0)
-        M = (A.T @ A).cpu()
-        evals, evecs = torch.linalg.eigh(M)
-        Pm = evecs[:, 0].reshape(3, 4)
-        U, S, Vt = torch.linalg.svd(Pm[:, :3])
-        sgn = torch.sign(torch.det(U @ Vt))
-        R = sgn * (U @ Vt)
-        scale = sgn * S.mean()
-        t = Pm[:, 3] / scale
-        Rd, td = R.to(dev), t.to(dev)
-        cam = X @ Rd.T + td
-        if float((cam[:, 2] > 0).double().mean()) < 0.5:                      # points must lie in front of the camera
-            R, t = -R, -t
-            R = R @ torch.diag(torch.tensor([1., 1., 1.], dtype=torch.float64))
-            Rd, td = R.to(dev), t.to(dev)
-            cam = X @ Rd.T + td
-        res = (cam[:, :2] / cam[:, 2:3].clamp(min=1e-9) - rays[:, :2]).norm(dim=-1) * focal      # reprojection error in pixels
-        best = (R, t)
-        wgt = 1.0 / res.clamp(min=1.0)                                        # Huber-like: down-weight > 1 px
-    R, t = best
-    if float(torch.det(R)) < 0:
-        return None
-    w2c = torch.eye(4, dtype=torch.float64)
-    w2c[:3, :3], w2c[:3, 3] = R, t
-    return focal, torch.linalg.inv(w2c).float().to(dev)
+def pnp_batched(problems, iterations=10):
+    """Camera-to-world poses of B images from their world-space point maps, ONE batch on the device (a3r_pnp_solve, csrc/init.hip) and
+    one synchronisation.  problems: list of (pts3d [H,W,3] float32 device, mask [H,W] bool device, focal float, pp (x, y) or None).
+    Each problem uses a regular subsample of at most PNP_MAX_POINTS pixels (plenty for a 6-dof fit; the reference's RANSAC draws
+    minimal sets).  Returns (info [B,4] numpy: valid, inliers (< 5 px, in front), truncated squared error, focal;  c2w [B,4,4] device)."""
+    from ... import _lib
+    from ..._lib import check, ptr, stream_ptr
+    lib = _lib.load()
+    B = len(problems)
+    home = problems[0][0].device
+    dev = home if home.type == "cuda" else torch.device("cuda")      # the solver runs on the GPU; host tensors are moved there
+    rec = np.zeros(B, dtype=np.dtype([('pts', '<u8'), ('msk', '<u8'), ('H', '<i4'), ('W', '<i4'), ('step', '<i4'), ('n', '<i4'),
+                                      ('focal', '<f4'), ('ppx', '<f4'), ('ppy', '<f4'), ('pad', '<f4')]))
+    assert rec.dtype.itemsize == int(lib.a3r_pnp_desc_bytes())
+    keep = []                                                     # the kernels read these buffers: keep them alive until the sync
+    for b, (pts, msk, focal, pp) in enumerate(problems):
+        H, W, _ = pts.shape
+        pts = pts.to(device=dev, dtype=torch.float32).contiguous()
+        m8 = msk.to(device=dev, dtype=torch.uint8).contiguous()
+        keep += [pts, m8]
+        step = -(-(H * W) // PNP_MAX_POINTS)
+        c = (W / 2, H / 2) if pp is None else pp
+        rec[b] = (pts.data_ptr(), m8.data_ptr(), H, W, step, -(-(H * W) // step), focal, c[0], c[1], 0.0)
+    n_max = int(rec['n'].max())
+    desc = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+    work = torch.empty(int(lib.a3r_pnp_work_bytes(B, n_max)), dtype=torch.uint8, device=dev)
+    c2w = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+    info = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.a3r_pnp_solve(ptr(desc), B, n_max, iterations, ptr(work), ptr(c2w), ptr(info), stream_ptr()), "a3r_pnp_solve")
+    info = info.cpu().numpy()                                     # the one synchronisation
+    del keep
+    return info, c2w.to(home)
+
+
+def pnp_focal_candidates(H, W):
+    """fast_pnp's focal search (:459-470): 21 focals in geomspace(S / 2, 3 S), S = max(W, H)."""
+    return [float(f) for f in np.geomspace(max(W, H) / 2, max(W, H) * 3, 21)]
+
+
+def linear_pnp_many(items, iterations=10):
+    """items: list of (pts3d [H,W,3], focal or None, mask [H,W], pp or None).  focal=None (an image that is never the first view of
+    an edge, e.g. the last frame of a non-symmetrised graph): like fast_pnp, try 21 focals and keep the one with the most inliers
+    (reprojection error < 5 px, in front of the camera; ties -- every point an inlier for several focals on a smooth scene -- go to
+    the smallest truncated squared error).  One device batch for everything.  Returns a list of None | (focal, c2w)."""
+    problems, owner = [], []
+    for k, (pts, focal, msk, pp) in enumerate(items):
+        for f in ([float(focal)] if focal is not None else pnp_focal_candidates(*pts.shape[:2])):
+            problems.append((pts, msk, f, pp))
+            owner.append(k)
+    if not problems:
+        return []
+    info, c2w = pnp_batched(problems, iterations)
+    out = [None] * len(items)
+    best = {}
+    for b, k in enumerate(owner):
+        valid, inl, err, f = info[b]
+        if not valid:
+            continue
+        if items[k][1] is not None:
+            out[k] = (float(f), c2w[b])
+        elif inl > 0 and (k not in best or (inl, -err) > best[k][0]):
+            best[k] = ((inl, -err), b)
+    for k, (_, b) in best.items():
+        out[k] = (float(info[b][3]), c2w[b])
+    return out
+
+
+def linear_pnp(pts3d, focal, msk, pp=None, iterations=10):
+    """Camera-to-world pose of an image whose pixels see the world points pts3d [H,W,3] (stands in for fast_pnp :442-482):
+    closed-form start + robust Gauss-Newton on the reprojection error, on the device (linear_pnp_many; `iterations` plays the
+    role of fast_pnp's niter_PnP).  Returns None | (focal, c2w [4,4])."""
+    return linear_pnp_many([(pts3d, focal, msk.to(pts3d.device), pp)], iterations)[0]
 
 
 # ------------------------------------------------------------------------------------------------ the tree
@@ -274,12 +324,11 @@ def minimum_spanning_tree(imshapes, edges, pred_i, pred_j, conf_i, conf_j, im_co
         for (i, j), _ in order:
             if im_focals[i] is None:
                 im_focals[i] = edge_focal[eidx[(i, j)]]
-        for i in range(n_imgs):
-            if im_poses[i] is None:
-                msk = (im_conf[i] > min_conf_thr).to(device)
-                res = linear_pnp(pts3d[i], im_focals[i], msk)
-                if res:
-                    im_focals[i], im_poses[i] = res
+        missing = [i for i in range(n_imgs) if im_poses[i] is None]            # every missing pose in ONE device batch
+        for i, res in zip(missing, linear_pnp_many([(pts3d[i], im_focals[i], (im_conf[i] > min_conf_thr).to(device), None) for i in missing])):
+            if res:
+                im_focals[i], im_poses[i] = res
+        for i in missing:
             if im_poses[i] is None:
                 im_poses[i] = torch.eye(4, device=device)
         im_poses = torch.stack(im_poses)
@@ -330,25 +379,25 @@ def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
     sols = rigid_points_registration_batched(eng.pred_i.reshape(E, P, 3),
                                              torch.stack([pad(p.reshape(-1, 3).float()) for p in pts3d]).contiguous(),
                                              scene._raw_conf_i.to(dev).reshape(E, P).float().contiguous(), [i for i, _ in scene.edges])
-    pw[:, 0:4] = torch.stack([rotmat_to_unitquat(R) for _, R, _ in sols]).to(dev)
-    pw[:, 4:7] = signed_log1p(torch.stack([T / s for s, _, T in sols])).to(dev)
-    pw[:, 7] = torch.tensor([float(np.log(s)) for s, _, _ in sols], device=dev)
-    s_factor = float(torch.exp(np.log(scene.base_scale) - pw[:, 7].mean())) if scene.norm_pw_scale else 1.0
+    pw[:, 0:4] = rotmat_to_unitquat_batched(sols[:, 1:10].reshape(E, 3, 3))
+    pw[:, 4:7] = signed_log1p(sols[:, 10:13] / sols[:, 0:1])
+    pw[:, 7] = sols[:, 0].log()
+    s_factor = torch.exp(np.log(scene.base_scale) - pw[:, 7].mean()) if scene.norm_pw_scale else 1.0      # stays on the device
     im_poses = im_poses.clone()
     im_poses[:, :3, 3] *= s_factor
     pts3d = [p * s_factor for p in pts3d]
     poses = eng.params['im_poses'].clone()
     depth = eng.params['depth'].clone()
     focals = eng.params['im_focals'].clone()
-    for i in range(N):
-        c2w = im_poses[i]
-        if not scene.if_use_mono:
-            w2c = torch.linalg.inv(c2w)
-            d = geotrf(w2c, pts3d[i].reshape(-1, 3))[:, 2]
+    if not scene.if_use_mono:
+        w2c = inv_rigid(im_poses)
+        for i in range(N):
+            d = geotrf(w2c[i], pts3d[i].reshape(-1, 3))[:, 2]
             depth[i] = pad(d).log().nan_to_num(neginf=0)          # _set_depthmap: _ravel_hw zero-fill, log(0) -> 0
-        if eng.flags['train_poses']:
-            poses[i, 0:4] = rotmat_to_unitquat(c2w[:3, :3]).to(dev)
-            poses[i, 4:7] = signed_log1p(c2w[:3, 3])
+    if eng.flags['train_poses']:
+        poses[:, 0:4] = rotmat_to_unitquat_batched(im_poses[:, :3, :3])
+        poses[:, 4:7] = signed_log1p(im_poses[:, :3, 3])
+    for i in range(N):
         if im_focals[i] is not None and eng.flags['train_focals'] and not getattr(eng, 'shared_focal', False):
             focals[i] = scene.focal_break * float(np.log(im_focals[i]))
     if getattr(eng, 'shared_focal', False) and eng.flags['train_focals'] and im_focals[0] is not None:
@@ -389,13 +438,15 @@ def init_from_known_poses(scene, niter_PnP=10, min_conf_thr=3):
     im_pp = scene.get_principal_points()
     pw = eng.params['pw_poses'].clone()
     best = {}
+    cmin = [float(c.min()) for c in conf_i]
+    focals_h, pp_h = im_focals.cpu().tolist(), im_pp.cpu().tolist()
+    pnp = linear_pnp_many([(pred_j[e], focals_h[i], conf_i[e] > min(min_conf_thr, cmin[e] - 0.1), (pp_h[i][0], pp_h[i][1]))
+                           for e, (i, j) in enumerate(scene.edges)])
     for e, (i, j) in enumerate(scene.edges):
         P1 = torch.eye(4, device=dev)
-        msk = conf_i[e] > min(min_conf_thr, float(conf_i[e].min()) - 0.1)
-        res = linear_pnp(pred_j[e], float(im_focals[i]), msk, pp=(float(im_pp[i, 0]), float(im_pp[i, 1])))
-        if res is None:
+        if pnp[e] is None:
             raise RuntimeError(f'PnP failed on edge ({i},{j})')
-        P2 = res[1]
+        P2 = pnp[e][1]
         s, R, T = align_multiple_poses(torch.stack((P1, P2)), known_poses[[i, j]])
         pw[e, 0:4] = rotmat_to_unitquat(R).to(dev)
         pw[e, 4:7] = signed_log1p(T.to(dev) / s)

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from ...aligner import AlignEngine
+from .init_im_poses import inv_rigid
 from .commons import get_conf_trf, get_imshapes, rotmat_to_unitquat, signed_expm1, signed_log1p, unitquat_to_rotmat
 
 
@@ -324,7 +325,7 @@ class PointCloudOptimizer:
 
     def clean_pointcloud(self, **kw):
         """base_opt.py:268-278: lower the confidence of points that another, more confident view sees through."""
-        cams = torch.linalg.inv(self.get_im_poses())
+        cams = inv_rigid(self.get_im_poses())
         new_confs = clean_pointcloud([c.to(self.device) for c in self.im_conf], self.get_intrinsics(), cams, self.get_depthmaps(),
                                      self.get_pts3d(), **kw)
         for i, c in enumerate(new_confs):

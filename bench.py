@@ -18,6 +18,7 @@ Contract (one JSON line on rank 0):
 from __future__ import annotations
 
 import argparse
+import math
 import json
 import os
 import sys
@@ -49,6 +50,32 @@ def pmc_traffic(kernel):
             return json.load(f)["kernels"][kernel]["traffic_bytes_per_launch"], os.path.basename(files[-1])
     except (KeyError, ValueError, OSError):
         return None, None
+
+
+def synthetic_pair_geometry(i, j, H, W, dev):
+    """Point maps of views i and j of a smooth synthetic surface, both in camera i's frame (what the network predicts for the pair
+    (i, j)), and a confidence map -- for the clip extra only."""
+    import torch
+    f = 1.2 * max(H, W)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float64), torch.arange(W, device=dev, dtype=torch.float64), indexing="ij")
+    rays = torch.stack(((xs - W / 2) / f, (ys - H / 2) / f, torch.ones_like(xs)), -1)
+
+    def cam(n):
+        a = 0.03 * n
+        R = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], device=dev, dtype=torch.float64)
+        return R, torch.tensor([0.1 * n, 0.02 * n, 0.01 * n], device=dev, dtype=torch.float64)
+
+    def world(n):
+        R, t = cam(n)
+        d = 3 + 0.8 * torch.sin(xs / W * 5 + 0.3 * n) * torch.cos(ys / H * 4)
+        return (rays * d[..., None]) @ R.T + t
+
+    Ri, ti = cam(i)
+    p1 = 0.7 * ((world(i) - ti) @ Ri)
+    p2 = 0.7 * ((world(j) - ti) @ Ri)
+    g = torch.Generator(device="cpu").manual_seed(1000 * i + j)
+    cf = (2 + 8 * torch.rand((H, W), generator=g)).to(dev)
+    return p1.float(), p2.float(), cf
 
 
 def parse():
@@ -261,8 +288,10 @@ def main():
                                          "(which re-encodes per pair), outputs bit-identical; NOT the headline value"}
 
     # ---- extra (not the headline): wall clock of the whole clip as a driver runs it -- pair inference of all E pairs, aligner
-    # construction, init='mst' (parity unpinned: DESIGN.md section 2) and 300 iterations.  Synthetic noise frames give point maps
-    # without a consistent geometry, so the numbers say what the steps COST, not what they converge to.
+    # construction, init='mst' (parity unpinned: DESIGN.md section 2) and 300 iterations.  Random-init weights turn any frames into
+    # point maps without a consistent geometry, so after the (timed) inference the prediction buffers are overwritten, outside the
+    # timed regions, with the pairwise point maps of a synthetic consistent scene of the same shapes: the aligner steps are timed on
+    # a problem they can actually solve, and final_loss says they did.
     if not a.no_clip_run and world == 1:
         try:
             from align3r_amd.dust3r.cloud_opt import global_aligner
@@ -278,6 +307,13 @@ def main():
                             out=dict(pts3d_1=P1[sl], conf_1=C1[sl], pts3d_2=P2[sl], conf_2=C2[sl]))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
+            for k, (i, j) in enumerate(edges):                     # untimed: consistent synthetic geometry (see above)
+                p1, p2, cf = synthetic_pair_geometry(i, j, H, W, dev)
+                P1[k], P2[k], C1[k], C2[k] = p1, p2, cf, cf
+            torch.cuda.synchronize()
+            t_fill = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            t0 += t_fill
             outp = dict(view1=dict(idx=[i for i, _ in edges]), view2=dict(idx=[j for _, j in edges]),
                         pred1=dict(pts3d=P1, conf=C1), pred2=dict(pts3d_in_other_view=P2, conf=C2))
             torch.manual_seed(0)
@@ -291,9 +327,11 @@ def main():
             torch.cuda.synchronize()
             t4 = time.perf_counter()
             res["clip_wall_clock"] = {"total_s": round(t4 - t0, 3), "inference_s": round(t1 - t0, 3), "aligner_build_s": round(t2 - t1, 3),
-                                      "init_mst_s": round(t3 - t2, 3), "iters300_s": round(t4 - t3, 3), "final_loss": round(float(loss), 5),
+                                      "init_mst_s": round(t3 - t2, 3), "iters300_s": round(t4 - t3, 3),
+                                      "final_loss": round(float(loss), 5) if math.isfinite(float(loss)) else None,
                                       "note": f"{a.frames} frames, {E} pairs, one GPU: inference of every pair + global_aligner + init='mst' + "
-                                              "300 cosine iterations; extra, not the headline"}
+                                              "300 cosine iterations (aligner steps on a synthetic consistent scene written into the "
+                                              "prediction buffers after the timed inference); extra, not the headline"}
             del scene, outp, P1, P2, C1, C2
         except Exception as ex:      # an extra must never take the headline down with it
             res["clip_wall_clock"] = {"error": f"{type(ex).__name__}: {ex}"}

@@ -267,6 +267,21 @@ int a3r_umeyama_chunks(int P);
 int a3r_umeyama_moments(const float* x, const float* y, const float* w, const long* x_off, const long* y_off, const long* w_off,
                         int B, int P, double* partial, void* stream);
 
+/* Closed-form weighted similarity registration of B problems from the raw moments of a3r_umeyama_moments (partial [B][nch][17]):
+ * out [B][13] = (s, R row-major [9], T [3]) minimising sum w |s R x + T - y|^2 -- 3x3 SVD by Jacobi on the device, one thread per
+ * problem (replaces roma.rigid_points_registration, init_im_poses.py:415-418). */
+int a3r_umeyama_solve(const double* partial, int nch, int B, float* out, void* stream);
+/* Batched camera pose from a world-space point map with known intrinsics (stands in for fast_pnp, init_im_poses.py:442-482; parity
+ * unpinned: cv2.solvePnPRansac is stochastic and absent).  desc: B device records of a3r_pnp_desc_bytes() bytes
+ * {const float* pts [H,W,3]; const uint8* mask [H,W]; int H, W, step, n; float focal, ppx, ppy, pad} -- the problem uses the n =
+ * ceil(H W / step) pixels p * step that the mask keeps.  Closed-form start + `iterations` robust Gauss-Newton steps on the reprojection error
+ * (Cauchy weights annealed to 5 px), float64, no host synchronisation.  c2w [B][16] camera-to-world;
+ * info [B][4] = (valid, inliers < 5 px in front of the camera, sum of min(e^2, 25 px^2) over the points in front, focal).  work: a3r_pnp_work_bytes(B, n_max). */
+size_t a3r_pnp_desc_bytes(void);
+int a3r_pnp_chunks(int n_max);
+size_t a3r_pnp_work_bytes(int B, int n_max);
+int a3r_pnp_solve(const void* desc, int B, int n_max, int iterations, void* work, float* c2w, float* info, void* stream);
+
 int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 /* the same, written in bf3 form ([B Hc Wc][C/8][3][8] bf16, C % 8 == 0): input of the next conv on the bf3 kernel */
 int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W, int C, int Hc, int Wc, void* stream);

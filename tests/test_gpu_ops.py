@@ -227,7 +227,10 @@ def test_umeyama_moments_kernel():
     W = (0.5 + rng.random((E, P))).astype(np.float32)
     yi = [e % N for e in range(E)]
     sols = rigid_points_registration_batched(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), torch.from_numpy(W).cuda(), yi)
-    for e, (s, Rr, T) in enumerate(sols):
+    assert sols.is_cuda and tuple(sols.shape) == (E, 13)          # solved on the device (Jacobi SVD, csrc/init.hip), stays there
+    sols_h = sols.cpu()
+    for e in range(E):
+        s, Rr, T = float(sols_h[e, 0]), sols_h[e, 1:10].reshape(3, 3), sols_h[e, 10:13]
         if e < N:            # x = X[e], y = similarity of X[e]: recovered exactly
             assert abs(s - 1.7) < 1e-4 and np.abs(Rr.numpy() - R).max() < 1e-5 and np.abs(T.numpy() - [0.3, -1.0, 2.0]).max() < 1e-4
         # against the float64 closed form on the host
@@ -241,4 +244,39 @@ def test_umeyama_moments_kernel():
         assert abs(s - s_ref) < 1e-5 * max(1, abs(s_ref))
         assert np.abs(Rr.numpy() - (U * d) @ Vt).max() < 1e-5
     s1, R1, T1 = rigid_points_registration(torch.from_numpy(X[0]).cuda(), torch.from_numpy(Y[0]).cuda(), torch.from_numpy(W[0]).cuda())
-    assert abs(s1 - sols[0][0]) < 1e-12 and torch.equal(R1, sols[0][1])          # same kernel, same order: bitwise
+    assert float(s1) == float(sols[0, 0]) and torch.equal(R1.reshape(9), sols[0, 1:10])          # same kernels, same order: bitwise
+
+
+def test_pnp_on_device():
+    """a3r_pnp_solve (csrc/init.hip; stands in for fast_pnp, init_im_poses.py:442-482, parity unpinned): a synthetic camera seeing a
+    smooth surface -- the pose is recovered with the true focal, also with 20 % and 40 % of the points displaced by gross outliers
+    (what the reference has RANSAC for), the focal search picks the candidate next to the true focal, a mask with fewer than six
+    points gives None, all in one batch."""
+    from align3r_amd.dust3r.cloud_opt.init_im_poses import linear_pnp_many, pnp_focal_candidates
+    rng = np.random.default_rng(1)
+    H, W, f = 96, 128, 150.0
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    d = 3 + 0.6 * np.sin(xs / W * 5) * np.cos(ys / H * 4)
+    cam = np.stack([(xs - W / 2) / f * d, (ys - H / 2) / f * d, d], -1)
+    a, b = 0.3, -0.2
+    Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    c2w = np.eye(4); c2w[:3, :3] = Ry @ Rx; c2w[:3, 3] = [0.4, -0.2, 1.0]
+    world = cam @ c2w[:3, :3].T + c2w[:3, 3]
+    def outliers(frac):
+        noisy = world.copy()
+        bad = rng.random((H, W)) < frac
+        noisy[bad] += rng.standard_normal((int(bad.sum()), 3))
+        return noisy
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    full = torch.ones(H, W, dtype=torch.bool, device="cuda")
+    few = torch.zeros(H, W, dtype=torch.bool, device="cuda"); few[0, :5] = True
+    res = linear_pnp_many([(t(world), f, full, None), (t(outliers(0.2)), f, full, None), (t(world), None, full, None), (t(world), f, few, None),
+                           (t(outliers(0.4)), f, full, None)])
+    for k, tol in ((0, 1e-4), (1, 3e-2), (4, 8e-2)):
+        assert res[k] is not None and res[k][0] == f
+        assert np.abs(res[k][1].cpu().numpy() - c2w).max() < tol, (k, res[k][1])
+    assert res[3] is None
+    cands = pnp_focal_candidates(H, W)
+    below, above = max(c for c in cands if c <= f), min(c for c in cands if c >= f)
+    assert res[2] is not None and (res[2][0] == pytest.approx(below, rel=1e-6) or res[2][0] == pytest.approx(above, rel=1e-6))

@@ -12,7 +12,21 @@ import sys
 
 KEYS = {"gemm_bf3_kernel<0": "gemm_bf3_kernel", "gemm_bf3_kernel<1": "gemm_bf3_kernel<1>", "attn_bf3_kernel": "attn_bf3_kernel",
         "gemm_kernel<0": "gemm_kernel<0>", "gemm_kernel<1": "gemm_kernel<1>", "attn_kernel": "attn_kernel",
-        "align_main_kernel": "align_main_kernel", "layernorm_kernel": "layernorm_kernel"}
+        "align_main_kernel": "align_main_kernel", "layernorm_kernel": "layernorm_kernel", "layernorm_pair_kernel": "layernorm_kernel",
+        "layernorm_fh2_kernel": "layernorm_fh2_kernel", "attn_fh2_kernel": "attn_fh2_kernel", "upsample2x_kernel": "upsample2x_kernel",
+        "head_final_kernel": "head_final_kernel"}
+
+
+def classify(name):
+    """kernel name of the trace -> key of the json; the fh2 GEMM's LAST template argument says linear (0) or implicit conv (1)."""
+    n = name.replace("a3r::", "").replace("void ", "")
+    if "gemm_fh2_kernel<" in n:
+        args = n[n.index("<") + 1:n.index(">")].split(",")
+        return "gemm_fh2_kernel<1>" if args[-1].strip() == "1" else "gemm_fh2_kernel"
+    for k, v in KEYS.items():
+        if k in n:
+            return v
+    return None
 
 
 def collect(path, counter):
@@ -20,11 +34,9 @@ def collect(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"]
-        for k, v in KEYS.items():
-            if k in name.replace("a3r::", "").replace("void ", ""):
-                per[v].append(float(r["Counter_Value"]))
-                break
+        key = classify(r["Kernel_Name"])
+        if key:
+            per[key].append(float(r["Counter_Value"]))
     return per
 
 
