@@ -37,6 +37,7 @@ __device__ __forceinline__ void fh2_wait_vmcnt_dyn(int n) {
 struct Fh2Args {
     GemmArgs g;
     float inv_wscale[4];      // per group: 1 / (power-of-two scale the weights were stored with)
+    int gm;                   // row tiles per L2 block: workgroup ids walk gm row tiles before the next column tile (1 = row-major tile order)
     int lab;                  // developer experiment (A3R_FH2_LAB): 1 = every tile LOADS operand tiles (m & 1, n & 1) -- all L2 hits
 };
 
@@ -142,7 +143,15 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     const int grp = wgid / g.tiles_per_group;
     wgid -= grp * g.tiles_per_group;
     const GroupPtrs& P = g.grp[grp];
-    const int tile_m = wgid / g.tiles_n, tile_n = wgid - tile_m * g.tiles_n;
+    // L2 blocking: the workgroups resident on an XCD at one time (a run of consecutive ids) cover gm row tiles x (run / gm) column
+    // tiles instead of one or two row tiles x all column tiles, so fewer distinct W tiles stream through the XCD's 4 MB L2 per A tile
+    int tile_m, tile_n;
+    {
+        const int per = fa.gm * g.tiles_n, sm = wgid / per, rem = wgid - sm * per;
+        const int rows = min(fa.gm, g.tiles_m - sm * fa.gm);
+        tile_n = rem / rows;
+        tile_m = sm * fa.gm + (rem - tile_n * rows);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -378,12 +387,17 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     GemmArgs& g = fa.g;
     g.direct_epilogue = 0;
     if (const char* l = getenv("A3R_FH2_LAB")) fa.lab = atoi(l);
+    static const int gm_env = getenv("A3R_FH2_GM") ? atoi(getenv("A3R_FH2_GM")) : 0;
     int t = choose_fh2_tile(g.M, g.N, g.groups);
     if (AMODE == 1 && t != 0) t = 2;                       // the implicit conv is built for tiles 0 and 2
     const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
     g.tiles_per_group = g.tiles_m * g.tiles_n;
+    // measured (tools/bench_fh2.py, A3R_FH2_GM=1|4|8|16): 8 row tiles per block is +6 % over the row-major order on the forward's
+    // K <= 1024 shapes (fc1 +11 %) and cuts the fabric bytes by a third; the K >= 3072 shapes (2 MB of A per row tile) lose 1-2 %
+    fa.gm = gm_env > 0 ? gm_env : (g.K >= 2048 ? 1 : 8);
+    if (fa.gm > g.tiles_m) fa.gm = g.tiles_m;
     const bool full = g.M % bm == 0 && g.N % bn == 0;
     const double mn = (double)g.M * g.N;
     const double c_bytes = mn * (4.0 + (g.epi.aux_fh2 ? 4.0 : 0.0) + (g.epi.epi == A3R_EPI_RESID ? 4.0 : g.epi.epi == A3R_EPI_RESID2 ? 8.0 : 0.0));

@@ -72,8 +72,16 @@ def record_margin(test, **values):
     out = os.path.join(REPO, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_margins.json"), "w") as f:
-            json.dump(_MARGINS, f, indent=1, sort_keys=True)
+        path = os.path.join(out, "parity_margins.json")
+        merged = {}
+        if os.path.exists(path):                       # keep what other test processes / earlier partial runs recorded
+            try:
+                merged = json.load(open(path))
+            except ValueError:
+                merged = {}
+        merged.update(_MARGINS)
+        with open(path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
     except OSError:
         pass
 
