@@ -28,7 +28,20 @@ struct GemmArgs {
     int direct_epilogue;    // A/B switch (env A3R_BF3_DIRECT_EPI): keep the accumulator-layout epilogue instead of the LDS-staged one
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU default, blocks.py:66) with erf from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, the size of an fp32 rounding of erf): q = 0.5 (1 - erf|z|) = 0.5 t (a1 + t (a2 + ...)) exp(-z^2),
+// t = 1 / (1 + p |z|); gelu = x (1 - q) for x >= 0 and x q for x < 0 -- no cancellation in the negative tail, one rcp + one exp2
+// and seven fma instead of the device library's branching erff (which cost +10 % on the fc1 GEMM, tools/bench_epi_fh2.py).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, z, 1.f));        // v_rcp_f32 (1 ulp)
+    float p = __fmaf_rn(t, 1.061405429f, -1.453152027f);
+    p = __fmaf_rn(t, p, 1.421413741f);
+    p = __fmaf_rn(t, p, -0.284496736f);
+    p = __fmaf_rn(t, p, 0.254829592f);
+    const float q = 0.5f * t * p * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // v_exp_f32: flushes below 2^-126, where q is 0 to fp32 anyway
+    return x >= 0.f ? __fmaf_rn(-x, q, x) : x * q;
+}
 
 // Epilogue over the 32x32 MFMA accumulators of one wave: acc[i][j] covers rows m0 + wrow0 + 32 i .. and columns
 // n0 + wcol0 + 32 j ..; element e of a lane sits at row (e&3) + 8 (e>>2) + 4 (lane>>5), column lane&31.
@@ -317,6 +330,20 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
     const int r_in = lane / LPR, c4 = (lane % LPR) * 4;
     const int gcol = n0 + wcol0 + c4;
     const bool col_ok = FULL || gcol < g.N;                  // N % 4 == 0 on this path: a float4 is in or out as a whole
+    // residual rows first, ALL of them, then the stores: the residual may alias y (the in-place residual stream), so the compiler
+    // must keep every load ahead of the later stores it could alias -- written as one loop that is a chain of ITERS dependent
+    // global round trips; a lane only ever stores where it loaded, so loading everything up front is safe
+    f32x4 rs[ITERS];
+    if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) {
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int grow = m0 + wrow0 + it * RPI + r_in;
+            const bool ok = col_ok && (FULL || grow < g.M);
+            const size_t o = (size_t)grow * g.ldc + gcol;
+            rs[it] = ok ? *reinterpret_cast<const f32x4*>(P.resid + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (epi == A3R_EPI_RESID2 && ok) rs[it] += *reinterpret_cast<const f32x4*>(P.resid2 + o);
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int rl = it * RPI + r_in;
@@ -325,8 +352,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
         const bool ok = col_ok && (FULL || grow < g.M);
         if (!ok) continue;
         const size_t o = (size_t)grow * g.ldc + gcol;
-        if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) v += *reinterpret_cast<const f32x4*>(P.resid + o);
-        if (epi == A3R_EPI_RESID2) v += *reinterpret_cast<const f32x4*>(P.resid2 + o);
+        if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) v += rs[it];
         *reinterpret_cast<f32x4*>(P.C + o) = v;
         if (out3 || out2) {
             if (relu3) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
