@@ -49,17 +49,30 @@ __device__ __forceinline__ int fh2_swz(int r) { return ((r >> 1) & 1) | (((r >> 
 // ---- out_fh2 epilogue: bias / GELU / ReLU in the accumulator layout, the two fp16 planes go to a wave-private LDS image shaped like
 // the final memory (32 rows x 128 bytes per 32-column block), and come back one 16-byte unit per lane: every store instruction
 // writes whole 128-byte lines.  lds: EPI_FH2_WAVE_BYTES per wave.
+// x / d and x % d for 0 <= x < 2^22, d > 0, inv = 1.f / d: the float quotient is off by at most one
+__device__ __forceinline__ int fast_div(int x, int d, float inv) {
+    int q = (int)((float)x * inv);
+    int r = x - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+__device__ __forceinline__ int fast_mod(int x, int d, float inv) { return x - fast_div(x, d, inv) * d; }
+
 constexpr int EPI_FH2_PITCH = 144;                       // bytes per image row (128 + 16: rows rotate over the banks)
 constexpr int EPI_FH2_WAVE_BYTES = 32 * EPI_FH2_PITCH;   // 4608
-template <int TM, bool FULL>
-__device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int n0, int wrow0,
-                                                 int wcol0, int lane, char* img) {
+// EPI: the epilogue kind as a compile-time constant (straight-line bodies: a per-element runtime switch splits the basic blocks and
+// keeps the compiler from packing the arithmetic of neighbouring elements)
+template <int TM, bool FULL, int EPI>
+__device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int n0, int wrow0,
+                                                      int wcol0, int lane, char* img) {
     static_assert(TM % 2 == 0, "halves of 32 rows");
     const a3r_epilogue& ep = g.epi;
     const int quad = lane >> 4, lcol = lane & 15;
     char* out = reinterpret_cast<char*>(P.C);
     const size_t pitch = fh2_row_bytes(g.N);
     const int kcol0 = n0 + wcol0;                            // a multiple of 32: one whole 128-byte k block of the output rows
+    const float inv_tokens = EPI == A3R_EPI_ROPE ? 1.f / (float)ep.tokens_per_image : 0.f;
+    const float inv_gw = EPI == A3R_EPI_ROPE ? 1.f / (float)ep.grid_w : 0.f;
 #pragma unroll
     for (int half = 0; half < TM / 2; half++) {
 #pragma unroll
@@ -70,43 +83,53 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
             const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
             // 2-D RoPE on the leading rope_cols columns (pairs (d, d + 16) inside each 32-wide half of a head, pos_embed.py:130-157):
             // the partner column is accumulator tile j ^ 1 of the same lane
-            const bool do_rope = ep.epi == A3R_EPI_ROPE && colbase < ep.rope_cols;       // wave-uniform (rope_cols % 64 == 0)
+            const bool do_rope = EPI == A3R_EPI_ROPE && colbase < ep.rope_cols;          // wave-uniform (rope_cols % 64 == 0)
             const float bias_o = (do_rope && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] : 0.f;
             const bool rope_x = (colbase & 32) != 0, second = (colbase & 16) != 0;
-            const int cw = j * 16 + lcol;
+            // a lane holds one column of four rows; the fh2 form packs neighbouring COLUMNS.  Neighbouring lanes (columns c, c + 1)
+            // trade half of their rows by DPP: the even lane ends up with rows e = 0, 1 of both columns, the odd lane with rows 2, 3,
+            // and each stores whole 4-byte pieces [col c | col c + 1] of a plane (2-byte stores of single elements ran into LDS
+            // bank conflicts: they were most of the 12 % an fh2 output cost over an fp32 one)
+            const int cw = j * 16 + (lcol & ~1);
+            const bool odd = lcol & 1;
             char* dcol = img + (cw >> 3) * 32 + (cw & 7) * 2;
 #pragma unroll
-            for (int il = 0; il < 2; il++)
+            for (int il = 0; il < 2; il++) {
+                const int i = half * 2 + il;
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const int i = half * 2 + il;
-                    float v[2];
-#pragma unroll
-                    for (int d = 0; d < 2; d++) {
-                        v[d] = acc[i][j][e + d] + bias;
-                        if (do_rope) {
-                            const int row = m0 + wrow0 + i * 16 + quad * 4 + e + d;
-                            const float other = acc[i][j ^ 1][e + d] + bias_o;
-                            const int tok = row % ep.tokens_per_image;
-                            const int py = tok / ep.grid_w, px = tok - py * ep.grid_w;
-                            const int pp = rope_x ? px : py;
-                            const float c = ep.rope_cos[pp * 16 + lcol], sn = ep.rope_sin[pp * 16 + lcol];
-                            // one rounding order for every element (a product, then one fused multiply-add): hipcc otherwise vectorises
-                            // the row pair and contracts its two halves differently, i.e. a row's result depends on its parity
-                            const float t = __fmul_rn(other, sn);
-                            v[d] = __fmaf_rn(v[d], c, second ? t : -t);
-                        }
-                        if (ep.epi == A3R_EPI_GELU) v[d] = gelu_erf(v[d]);
-                        else if (ep.epi == A3R_EPI_RELU) v[d] = fmaxf(v[d], 0.f);
+                for (int e = 0; e < 4; e++) {
+                    v[e] = acc[i][j][e] + bias;
+                    if (do_rope) {
+                        const int row = m0 + wrow0 + i * 16 + quad * 4 + e;
+                        const float other = acc[i][j ^ 1][e] + bias_o;
+                        // token position without integer division (two runtime divisions per element were most of this
+                        // epilogue's cost): exact for row < 2^22 by a float quotient and one correction step each way
+                        const int tok = fast_mod(row, ep.tokens_per_image, inv_tokens);
+                        const int py = fast_div(tok, ep.grid_w, inv_gw), px = tok - py * ep.grid_w;
+                        const int pp = rope_x ? px : py;
+                        const float c = ep.rope_cos[pp * 16 + lcol], sn = ep.rope_sin[pp * 16 + lcol];
+                        // one rounding order for every element (a product, then one fused multiply-add): hipcc otherwise vectorises
+                        // row pairs and contracts their halves differently, i.e. a row's result depends on its parity
+                        const float t = __fmul_rn(other, sn);
+                        v[e] = __fmaf_rn(v[e], c, second ? t : -t);
                     }
-                    uint32_t p0, p1;
-                    fh2_split2(v[0], v[1], p0, p1);                  // low half: row e, high half: row e + 1
-                    char* d = dcol + (il * 16 + quad * 4 + e) * EPI_FH2_PITCH;
-                    *reinterpret_cast<uint16_t*>(d) = (uint16_t)p0;
-                    *reinterpret_cast<uint16_t*>(d + 16) = (uint16_t)p1;
-                    *reinterpret_cast<uint16_t*>(d + EPI_FH2_PITCH) = (uint16_t)(p0 >> 16);
-                    *reinterpret_cast<uint16_t*>(d + EPI_FH2_PITCH + 16) = (uint16_t)(p1 >> 16);
+                    if (EPI == A3R_EPI_GELU) v[e] = gelu_erf(v[e]);
+                    else if (EPI == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                 }
+                // send the rows the neighbour keeps, receive its values of the rows this lane keeps
+                const float g0 = dpp_xor1(odd ? v[0] : v[2]), g1 = dpp_xor1(odd ? v[1] : v[3]);
+                const float l0 = odd ? g0 : v[0], r0 = odd ? v[2] : g0;       // kept row 0: (column c, column c + 1)
+                const float l1 = odd ? g1 : v[1], r1 = odd ? v[3] : g1;       // kept row 1
+                uint32_t a0, a1, b0, b1;
+                fh2_split2(l0, r0, a0, a1);
+                fh2_split2(l1, r1, b0, b1);
+                char* d = dcol + (il * 16 + quad * 4 + (odd ? 2 : 0)) * EPI_FH2_PITCH;
+                *reinterpret_cast<uint32_t*>(d) = a0;
+                *reinterpret_cast<uint32_t*>(d + 16) = a1;
+                *reinterpret_cast<uint32_t*>(d + EPI_FH2_PITCH) = b0;
+                *reinterpret_cast<uint32_t*>(d + EPI_FH2_PITCH + 16) = b1;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -120,6 +143,17 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                       // the reads are done before the next half overwrites the image
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int TM, bool FULL>
+__device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int n0, int wrow0,
+                                                 int wcol0, int lane, char* img) {
+    switch (g.epi.epi) {                                           // wave-uniform
+        case A3R_EPI_GELU: fh2_epilogue_out_body<TM, FULL, A3R_EPI_GELU>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
+        case A3R_EPI_RELU: fh2_epilogue_out_body<TM, FULL, A3R_EPI_RELU>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
+        case A3R_EPI_ROPE: fh2_epilogue_out_body<TM, FULL, A3R_EPI_ROPE>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
+        default: fh2_epilogue_out_body<TM, FULL, A3R_EPI_NONE>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
     }
 }
 
@@ -476,6 +510,7 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
     if (epi) g.epi = *epi;
     A3R_CHECK_ARG(!g.epi.relu_a && !g.epi.x_pair && !g.epi.out_pair, "a3r_linear_fh2: relu_a / x_pair / out_pair do not apply to fh2 operands");
     A3R_CHECK_ARG(g.epi.epi != A3R_EPI_PIXSHUF, "a3r_linear_fh2: PIXSHUF is not available");
+    A3R_CHECK_ARG(g.epi.epi != A3R_EPI_ROPE || M < (1 << 22), "a3r_linear_fh2: the ROPE epilogue takes at most 2^22 rows (got %d)", M);
     if (g.epi.aux_fh2)
         A3R_CHECK_ARG(!g.epi.out_fh2 && !g.epi.out_bf3 && N % 8 == 0 && ldc == N && g.epi.epi != A3R_EPI_PIXSHUF &&
                           (reinterpret_cast<uintptr_t>(g.epi.aux_fh2) & 15) == 0,
