@@ -28,7 +28,7 @@ constexpr int A4_KS_BYTES = A4K * A4_KROW;  // one K tile (two of them)
 constexpr int A4_VROW = 9 * 16;             // V^T row: 64 keys x 2 B + 1 pad unit
 constexpr int A4_VT_BYTES = 2 * 64 * A4_VROW;   // V^T tile: 2 planes x 64 d
 constexpr int A4_LDS_BYTES = 2 * A4_KS_BYTES + A4_VT_BYTES;   // 53,248 B
-constexpr float A4_PSCALE = 1024.f;
+constexpr float A4_PSHIFT = 10.f;     // P is carried as 2^10 p in its two fp16 planes (p <= 1: 1024 p keeps 21+ bits above fp16's subnormal range)
 
 struct Attn4Args {
     const char *q, *k, *v;
@@ -165,10 +165,13 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
             const float m_new = fmaxf(m_run, mx);        // finite: block kb = 0 of every tile has a valid key, and m_run carries it on
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
             m_run = m_new;
+            // p 2^10 = exp2(s c - m c + 10) by ONE fma per element: the power of two that the fp16 planes of P need (A4_PSCALE) rides
+            // in the exponent, and l accumulates the scaled values (an exact scaling: O / l is unchanged)
+            const float off = __fmaf_rn(-m_new, SCALE_LOG2E, A4_PSHIFT);
             float lsum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const float p = __builtin_amdgcn_exp2f((s[e] - m_new) * SCALE_LOG2E);
+                const float p = __builtin_amdgcn_exp2f(__fmaf_rn(s[e], SCALE_LOG2E, off));
                 s[e] = p;
                 lsum += p;
             }
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
 #pragma unroll
                 for (int mm = 0; mm < 4; mm++) {
                     uint32_t p0, p1;
-                    fh2_split2(s[8 * s2 + 2 * mm] * A4_PSCALE, s[8 * s2 + 2 * mm + 1] * A4_PSCALE, p0, p1);
+                    fh2_split2(s[8 * s2 + 2 * mm], s[8 * s2 + 2 * mm + 1], p0, p1);
                     pf[0][mm] = p0; pf[1][mm] = p1;
                 }
                 const f16x8 b0 = __builtin_bit_cast(f16x8, pf[0]), b1 = __builtin_bit_cast(f16x8, pf[1]);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.f / (l_tot * A4_PSCALE);            // the P planes carried the factor 1024 (an exact power of two)
+    const float inv_l = 1.f / l_tot;                          // P and l both carry the factor 2^10: it cancels
     if (q_row < a.Nq) {
         // lane (query, half) holds d = 32 db + 8 g + 4 half + (0..3): half of each plane's unit
         char* op = a.o + ((size_t)b * a.Nq + q_row) * a.po;
