@@ -246,33 +246,39 @@ __global__ void patchify_kernel(const float* __restrict__ img, float* __restrict
 // ------------------------------------------------------------------------------------------- bilinear x2, align_corners=True
 // Index arithmetic in fp32 exactly as ATen's upsample_bilinear2d (scale = (in-1)/(out-1); src = scale*dst).
 // BF3: write the result in bf3 form (rows = output pixels, K = C) -- the input of the following 1x1 / 3x3 conv on the bf3 kernel.
-// FMT 0: fp32, 1: bf3, 2: fh2 output
+// FMT 0: fp32, 1: bf3, 2: fh2 output.  Grid: x over (output column, channel quad) of one output row, y over (batch, output row):
+// the row / batch decomposition is scalar work once per workgroup and a thread does ONE 32-bit division (the first version took
+// three 64-bit divisions by runtime values per thread and ran at 2.6 TB/s, i.e. it was bound by them, not by memory).
 template <int FMT>
-__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
-                                  int Hc, int Wc) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
+                                                         int Hc, int Wc) {
     const float sh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float sw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
-    const long total = (long)B * Hc * Wc * C4;
     const f32x4* xv = reinterpret_cast<const f32x4*>(x);
     f32x4* yv = reinterpret_cast<f32x4*>(y);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4);
-        long t = i / C4;
-        const int ox = (int)(t % Wc); t /= Wc;
-        const int oy = (int)(t % Hc);
-        const int b = (int)(t / Hc);
-        const float fy = sh * (float)oy, fx = sw * (float)ox;
-        int y0 = (int)fy, x0 = (int)fx;
-        y0 = y0 < H - 1 ? y0 : H - 1; x0 = x0 < W - 1 ? x0 : W - 1;
-        const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
-        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned ox = idx / (unsigned)C4, c = idx - ox * (unsigned)C4;
+    if (ox >= (unsigned)Wc) return;
+    const float fx = sw * (float)ox;
+    int x0 = (int)fx;
+    x0 = x0 < W - 1 ? x0 : W - 1;
+    const int x1 = x0 < W - 1 ? x0 + 1 : x0;
+    const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    for (int row = blockIdx.y; row < B * Hc; row += gridDim.y) {   // (batch, output row): uniform per workgroup
+        const int b = row / Hc, oy = row - b * Hc;
+        const float fy = sh * (float)oy;
+        int y0 = (int)fy;
+        y0 = y0 < H - 1 ? y0 : H - 1;
+        const int y1 = y0 < H - 1 ? y0 + 1 : y0;
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
         const long rb = (long)b * H;
         const f32x4 v00 = xv[((rb + y0) * W + x0) * C4 + c], v01 = xv[((rb + y0) * W + x1) * C4 + c];
         const f32x4 v10 = xv[((rb + y1) * W + x0) * C4 + c], v11 = xv[((rb + y1) * W + x1) * C4 + c];
         const f32x4 o = (v00 * lx0 + v01 * lx1) * ly0 + (v10 * lx0 + v11 * lx1) * ly1;
-        if (FMT == 1) bf3_store4(reinterpret_cast<char*>(y) + (i / C4) * ((size_t)C4 * 24), c * 4, o);
-        else if (FMT == 2) fh2_store4(reinterpret_cast<char*>(y) + (i / C4) * ((size_t)C4 * 16), c * 4, o);
-        else yv[i] = o;
+        const long pix = (long)row * Wc + ox;
+        if (FMT == 1) bf3_store4(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 24), c * 4, o);
+        else if (FMT == 2) fh2_store4(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 16), c * 4, o);
+        else yv[pix * C4 + c] = o;
     }
 }
 
@@ -501,13 +507,18 @@ extern "C" int a3r_patchify(const float* img, float* cols, int B, int C, int H, 
     return A3R_OK;
 }
 
+static inline dim3 upsample_grid(int B, int Hc, int Wc, int C4) {
+    const long rows = (long)B * Hc;
+    return dim3((unsigned)(((long)Wc * C4 + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535));
+}
+
 extern "C" int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream) {
     A3R_CHECK_ARG(x && y, "a3r_upsample2x: null pointer");
     A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "a3r_upsample2x: bad shape");
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
+    hipLaunchKernelGGL(upsample2x_kernel<0>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -518,7 +529,7 @@ extern "C" int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W,
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_bf3: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 24.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y3), B, H, W,
+    hipLaunchKernelGGL(upsample2x_kernel<1>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y3), B, H, W,
                        C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
@@ -530,7 +541,7 @@ extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W,
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_fh2: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
+    hipLaunchKernelGGL(upsample2x_kernel<2>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
                        C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -42,6 +42,23 @@ def check_if_same_size(pairs):
     return all(shapes1[0] == s for s in shapes1) and all(shapes2[0] == s for s in shapes2)
 
 
+def _check_finite(out):
+    """The default arithmetic (A3R_GEMM=fh2) carries activations as fp16 planes: |activation| must stay below 65504, which holds by
+    a wide margin for LayerNorm-ed transformers but is a property of the checkpoint, not a guarantee.  An overflow surfaces as Inf /
+    NaN in the confidences; fail loudly and name the switch with fp32 range instead of returning garbage.  One reduction over the
+    collected confidences per inference() call (A3R_CHECK_FINITE=0 skips it)."""
+    if os.environ.get('A3R_CHECK_FINITE', '1') == '0':
+        return out
+    for side in ('pred1', 'pred2'):
+        conf = out[side].get('conf')
+        for c in (conf if isinstance(conf, (list, tuple)) else [conf]):
+            if c is not None and not bool(torch.isfinite(c).all()):
+                raise RuntimeError("align3r_amd inference produced non-finite confidences: an activation left the fp16 range of the "
+                                   "default fh2 arithmetic (or the inputs / weights are not finite); rerun with A3R_GEMM=bf3 "
+                                   "(same accuracy, fp32 range)")
+    return out
+
+
 def _inference_cached(pairs, model, device, batch_size, keep_on_device):
     """Encode every distinct frame once (keyed by view['idx']), then run decoders + heads per batch of pairs."""
     frames = {}
@@ -67,7 +84,7 @@ def _inference_cached(pairs, model, device, batch_size, keep_on_device):
         pred1, pred2 = model.forward_cached(view1, view2, f1, f2)
         res = dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=None)
         result.append(res if keep_on_device else to_cpu(res))
-    return collate_with_cat(result)
+    return _check_finite(collate_with_cat(result))
 
 
 @torch.no_grad()
@@ -103,4 +120,4 @@ def inference(pairs, model, device, batch_size=8, verbose=True, keep_on_device=F
         for side in ('pred1', 'pred2'):
             if isinstance(out[side].get('pred_mask'), list):
                 out[side]['pred_mask'] = [0] * asked_batches
-    return out
+    return _check_finite(out)

@@ -391,7 +391,9 @@ def main():
         model_np.forward(i0, i1, p0, p1, sd, VITL)
         tc = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                               "sample": f"1 pair {W}x{H} ViT-L through oracle/model_np.py (numpy + BLAS threads), {tc:.1f} s"}
+                               "sample": f"1 pair {W}x{H} ViT-L through oracle/model_np.py (numpy + BLAS threads), {tc:.1f} s",
+                               "note": "numpy port of the forward (GEMMs in the host BLAS, everything else single-threaded numpy): a reported baseline, "
+                                       "not an optimised CPU implementation; the aligner figure is the C/OpenMP oracle"}
         if not a.no_align:
             rng = np.random.default_rng(2)
             o = AlignOracle([i for i, j in edges], [j for i, j in edges], rng.standard_normal((E, P, 3), dtype=np.float32),
