@@ -235,10 +235,10 @@ def main():
         "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "gemm_mode": mode,
-        "dtype_note": ("fp32 in / fp32 out / fp32 accumulate.  Transformer GEMMs (A3R_GEMM=fh2, default): both operands split into two fp16 "
-                       "planes (22 significant bits), 3 exact fp16 MFMA passes -- error vs float64 not larger than the exact-fp32 MFMA GEMM's "
-                       "(tests/test_gpu_fh2.py); attention products and DPT convolutions: exact three-plane bf16 splits, 6 bf16 MFMA passes "
-                       "(tests/test_gpu_bf3.py).  A3R_GEMM=bf3 runs every GEMM on the exact three-plane form, A3R_GEMM=f32 on "
+        "dtype_note": ("fp32 in / fp32 out / fp32 accumulate.  Every matrix-core kernel (A3R_GEMM=fh2, default: transformer GEMMs, DPT 3x3 "
+                       "convolutions, attention products) splits both fp32 operands into two fp16 planes (22 significant bits) and runs 3 exact "
+                       "fp16 MFMA passes -- error vs float64 not larger than the exact-fp32 MFMA kernels' (tests/test_gpu_fh2.py).  "
+                       "A3R_GEMM=bf3 runs them on the exact three-plane bf16 form (6 passes, tests/test_gpu_bf3.py), A3R_GEMM=f32 on "
                        "v_mfma_f32_32x32x2_f32"),
         "config": {"workload": f"{a.frames}-frame synthetic clip {W}x{H}, ViT-L, {a.scene_graph} symmetrised (E={E}), "
                                f"{B} pairs/step/GPU, cloud_opt PointCloudOptimizer", "pairs_per_step_per_gpu": B,
