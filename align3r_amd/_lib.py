@@ -134,6 +134,7 @@ SIGNATURES = {
     "a3r_align_depth_prior_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "a3r_align_set_depth_prior": (C.c_int, [c_void, C.c_float, c_void, c_void, c_void, C.c_size_t, c_void]),
     "a3r_align_step_epoch": (C.c_int, [c_void, C.c_float, C.c_int, c_void]),
+    "a3r_align_run": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void]),
     "a3r_align_grad_epoch": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_void]),
     "a3r_align_grad_full": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "a3r_align_flow_state": (C.c_int, [c_void, c_void]),

@@ -265,8 +265,10 @@ class AlignEngine:
         """global_alignment_loop (base_opt.py:424-447) without per-iteration host syncs; returns the losses."""
         total = total_iters or niter
         start = self.steps_done
-        for it in range(first_iter, first_iter + niter):
-            self.step(schedule_lr(schedule, it / total, lr, lr_min), epoch=it)
+        # the schedule is evaluated here (float64, as the reference does), the iterations are enqueued by one native loop
+        lrs = np.asarray([schedule_lr(schedule, it / total, lr, lr_min) for it in range(first_iter, first_iter + niter)], dtype=np.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.a3r_align_run(self.handle, lrs.ctypes.data_as(C.c_void_p), int(niter), int(first_iter), stream_ptr()), "a3r_align_run")
         return self.loss_history[start:start + niter].cpu().numpy().astype(np.float64)
 
     def pose_matrices(self):

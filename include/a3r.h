@@ -393,6 +393,9 @@ int a3r_align_destroy(a3r_align_t a);
 /* One global_alignment_iter (base_opt.py:450-464): loss + gradients + Adam(betas .9,.9, eps 1e-8) with
  * learning rate lr.  Fully asynchronous; the loss lands in loss_history[step]. */
 int a3r_align_step(a3r_align_t a, float lr, void* stream);
+/* n iterations in one call: lrs_host[k] is the learning rate of iteration k (host array; the caller evaluates its schedule),
+ * epochs first_epoch .. first_epoch + n - 1.  Same results as n a3r_align_step_epoch calls, without a host round trip each. */
+int a3r_align_run(a3r_align_t a, const float* lrs_host, int n, int first_epoch, void* stream);
 /* Loss only (net() without backward), written to *loss_dev (device float). */
 int a3r_align_loss(a3r_align_t a, float* loss_dev, void* stream);
 /* Gradients of the current state without updating (for the parity tests):
