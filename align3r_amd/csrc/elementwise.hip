@@ -330,6 +330,54 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
     }
 }
 
+// C == 128 (the DPT head's last_dim): 8 lanes per pixel, a lane owns 16 consecutive channels = 64 contiguous bytes, so a wave reads
+// 8 pixels = 4 KB contiguous per step (the 32-lanes-per-pixel form above has 1 KB per step in flight and re-loads its four weight
+// vectors every pixel); the 4 x 16 weights of a lane stay in registers; three exchange steps finish the four dot products.
+__global__ __launch_bounds__(256) void head_final128_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ pts,
+                                                             float* __restrict__ conf, long P) {
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    f32x4 wr[4][4];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) wr[o][q] = reinterpret_cast<const f32x4*>(w + o * 128)[sub * 4 + q];
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const long iters = (P + nwaves * 8 - 1) / (nwaves * 8);       // uniform trip count: the exchanges need every lane
+    for (long it = 0; it < iters; it++) {
+        const long pix = (it * nwaves + wave) * 8 + (lane >> 3);
+        const bool ok = pix < P;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(x + pix * 128) + sub * 4;
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = xr[q];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[o] += v[q].x * wr[o][q].x + v[q].y * wr[o][q].y + v[q].z * wr[o][q].z + v[q].w * wr[o][q].w;
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            acc[o] += __shfl_xor(acc[o], 1);
+            acc[o] += __shfl_xor(acc[o], 2);
+            acc[o] += __shfl_xor(acc[o], 4);
+        }
+        if (ok && sub == 0) {
+            const float a0 = acc[0] + b0, a1 = acc[1] + b1, a2 = acc[2] + b2, a3 = acc[3] + b3;
+            // reference order: xyz / d.clip(1e-8) * expm1(d)   (postprocess.py:37-46)
+            const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+            const float dd = fmaxf(d, 1e-8f), em = expm1f(d);
+            pts[pix * 3 + 0] = a0 / dd * em;
+            pts[pix * 3 + 1] = a1 / dd * em;
+            pts[pix * 3 + 2] = a2 / dd * em;
+            conf[pix] = 1.f + expf(a3);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- weight repacking
 // [Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin]
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
@@ -563,7 +611,13 @@ extern "C" int a3r_head_final(const float* x, const float* w, const float* b, fl
     long blocks = (P + 7) / 8;
     if (blocks > 16384) blocks = 16384;
     ProfScope prof(PK_ELEMENTWISE, 4.0 * P * (C + 4), as_stream(stream));
-    hipLaunchKernelGGL(head_final_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, w, b, pts3d, conf, P, C);
+    if (C == 128 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        long nb = (P + 31) / 32;                                   // a block of four waves takes 32 pixels per step
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(head_final128_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), x, w, b, pts3d, conf, P);
+    } else {
+        hipLaunchKernelGGL(head_final_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, w, b, pts3d, conf, P, C);
+    }
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
