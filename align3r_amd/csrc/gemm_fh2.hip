@@ -304,18 +304,28 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
         }
 #pragma unroll
         for (int i = 0; i < TM; i++) {
+            // per accumulator the terms are added smallest first (x1 w0, x0 w1, x0 w0); across the row's accumulators the products of the
+            // SECOND plane of A go first, so that plane's registers can be re-filled for the next stage four MFMAs earlier
+            if constexpr (LAB == 2 || LAB == 4) {
 #pragma unroll
-            for (int j = 0; j < TN; j++) {                     // smallest terms first
-                if constexpr (LAB == 2 || LAB == 4) { acc[i][j][0] += (float)af[i][1][0] + (float)bc[j][1][0] + (float)af[i][0][1] + (float)bc[j][0][1]; continue; }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) acc[i][j][0] += (float)af[i][1][0] + (float)bc[j][1][0] + (float)af[i][0][1] + (float)bc[j][0][1];
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
+                if constexpr (NEXT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    af[i][1] = *reinterpret_cast<const f16x8*>(sb + offA[1] + i * 16 * U * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
             }
             if constexpr (NEXT) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (LAB == 5 && i + 1 < 4 && (wave >> 2) == i + 1 && kt + NS < nk) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
-#pragma unroll
-                for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(sb + offA[p] + i * 16 * U * 16);
+                af[i][0] = *reinterpret_cast<const f16x8*>(sb + offA[0] + i * 16 * U * 16);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
