@@ -251,18 +251,35 @@ __global__ void patchify_kernel(const float* __restrict__ img, float* __restrict
 // ------------------------------------------------------------------------------------------- bilinear x2, align_corners=True
 // Index arithmetic in fp32 exactly as ATen's upsample_bilinear2d (scale = (in-1)/(out-1); src = scale*dst).
 // BF3: write the result in bf3 form (rows = output pixels, K = C) -- the input of the following 1x1 / 3x3 conv on the bf3 kernel.
-// FMT 0: fp32, 1: bf3, 2: fh2 output.  Grid: x over (output column, channel quad) of one output row, y over (batch, output row):
+// one fixed rounding order for the interpolation in every output format (products and fused multiply-adds spelled out: left to
+// contraction the fp32 and the fh2 kernels would round differently and "fh2 output == split of the fp32 output" would not hold)
+__device__ __forceinline__ f32x4 bilerp4(f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11, float lx0, float lx1, float ly0, float ly1) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float t0 = __fmaf_rn(v01[e], lx1, __fmul_rn(v00[e], lx0));
+        const float t1 = __fmaf_rn(v11[e], lx1, __fmul_rn(v10[e], lx0));
+        o[e] = __fmaf_rn(t1, ly1, __fmul_rn(t0, ly0));
+    }
+    return o;
+}
+
+// FMT 0: fp32, 1: bf3, 2: fh2 output.  Grid: x over (output column, channel group) of one output row, y over (batch, output row):
 // the row / batch decomposition is scalar work once per workgroup and a thread does ONE 32-bit division (the first version took
-// three 64-bit divisions by runtime values per thread and ran at 2.6 TB/s, i.e. it was bound by them, not by memory).
+// three 64-bit divisions by runtime values per thread).  A thread produces 4 channels (fp32 / bf3) or 8 channels (fh2: the two
+// planes' 16-byte units of one 8-k group = 32 contiguous bytes, and half the index arithmetic per element -- PMC showed the
+// 4-channel fh2 form VALU-bound at 150 instructions per thread).
 template <int FMT>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
                                                          int Hc, int Wc) {
+    constexpr int Q = FMT == 2 ? 2 : 1;                        // float4 per thread
     const float sh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float sw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
     const f32x4* xv = reinterpret_cast<const f32x4*>(x);
     f32x4* yv = reinterpret_cast<f32x4*>(y);
+    const unsigned CG = (unsigned)C4 / Q;                      // channel groups per pixel
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
-    const unsigned ox = idx / (unsigned)C4, c = idx - ox * (unsigned)C4;
+    const unsigned ox = idx / CG, c = (idx - ox * CG) * Q;     // c: first float4 of this thread
     if (ox >= (unsigned)Wc) return;
     const float fx = sw * (float)ox;
     int x0 = (int)fx;
@@ -277,13 +294,16 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
         const int y1 = y0 < H - 1 ? y0 + 1 : y0;
         const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
         const long rb = (long)b * H;
-        const f32x4 v00 = xv[((rb + y0) * W + x0) * C4 + c], v01 = xv[((rb + y0) * W + x1) * C4 + c];
-        const f32x4 v10 = xv[((rb + y1) * W + x0) * C4 + c], v11 = xv[((rb + y1) * W + x1) * C4 + c];
-        const f32x4 o = (v00 * lx0 + v01 * lx1) * ly0 + (v10 * lx0 + v11 * lx1) * ly1;
+        const f32x4* r0 = xv + (rb + y0) * W * C4 + c;
+        const f32x4* r1 = xv + (rb + y1) * W * C4 + c;
+        f32x4 o[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            o[q] = bilerp4(r0[(long)x0 * C4 + q], r0[(long)x1 * C4 + q], r1[(long)x0 * C4 + q], r1[(long)x1 * C4 + q], lx0, lx1, ly0, ly1);
         const long pix = (long)row * Wc + ox;
-        if (FMT == 1) bf3_store4(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 24), c * 4, o);
-        else if (FMT == 2) fh2_store4(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 16), c * 4, o);
-        else yv[pix * C4 + c] = o;
+        if (FMT == 1) bf3_store4(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 24), c * 4, o[0]);
+        else if (FMT == 2) fh2_store8(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 16), c * 4, o[0], o[Q - 1]);
+        else yv[pix * C4 + c] = o[0];
     }
 }
 
@@ -564,9 +584,9 @@ extern "C" int a3r_patchify(const float* img, float* cols, int B, int C, int H, 
     return A3R_OK;
 }
 
-static inline dim3 upsample_grid(int B, int Hc, int Wc, int C4) {
+static inline dim3 upsample_grid(int B, int Hc, int Wc, int groups) {      // groups: threads per output pixel
     const long rows = (long)B * Hc;
-    return dim3((unsigned)(((long)Wc * C4 + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535));
+    return dim3((unsigned)(((long)Wc * groups + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535));
 }
 
 extern "C" int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream) {
@@ -598,7 +618,7 @@ extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W,
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_fh2: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<2>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
+    hipLaunchKernelGGL(upsample2x_kernel<2>, upsample_grid(B, Hc, Wc, C / 8), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
                        C / 4, Hc, Wc);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
