@@ -39,7 +39,7 @@ def run(N, H, W, graph, mono, iters=100, flow=False):
     _lib.prof_enable(False)
     r = {p["name"]: p for p in _lib.prof_report()}
     main, small = r["align_main_kernel"], r["align_finalize/prep kernels"]
-    print(f"N={N} E={E} P={P} mono={mono} flow={flow} tail={os.environ.get('A3R_ALIGN_TAIL', 'fused')}: {iters/dt_plain:8.1f} it/s un-profiled, {iters/dt:8.1f} it/s profiled  main {1e3*main['ms']/main['launches']:7.1f} us  "
+    print(f"N={N} E={E} P={P} mono={mono} flow={flow} tail={os.environ.get('A3R_ALIGN_TAIL', 'launch')}: {iters/dt_plain:8.1f} it/s un-profiled, {iters/dt:8.1f} it/s profiled  main {1e3*main['ms']/main['launches']:7.1f} us  "
           f"{main['work']/main['ms']/1e6:7.1f} GB/s  small {1e3*small['ms']/max(small['launches'],1):6.1f} us  loss {losses[0]:.4f}->{losses[-1]:.4f}", flush=True)
 
 if __name__ == "__main__":
