@@ -189,6 +189,12 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
         twin_lin("patch_embed_point_cloud.proj.weight", D, 768);
         twin_lin("decoder_embed.weight", D, E);
         for (int i = 0; i <= n_pc_blocks(c); i++) twin_lin("zero_convs." + std::to_string(i) + ".0.weight", D, D);
+        if (m->use_fh2)        // the 1x1 adapters of the DPT heads (act_postprocess.*.0): [layer_dim, D or E, 1, 1] = an nn.Linear weight
+            for (int h = 1; h <= 2; h++) {
+                const std::string p = "downstream_head" + std::to_string(h) + ".dpt.act_postprocess.";
+                twin_lin(p + "0.0.weight", c.layer_dims[0], E);
+                for (int i = 1; i < 4; i++) twin_lin(p + std::to_string(i) + ".0.weight", c.layer_dims[i], D);
+            }
         // DPT heads: every packed 3x3 conv weight [Cout, 9 Cin] and the 1x1 out_conv of the fusion blocks
         std::vector<PackItem> convs;
         for (const PackItem& it : v)
@@ -894,8 +900,16 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         const float* t3 = dec_last + (size_t)s * BN * D;
         const int h3 = (nh + 2 - 3) / 2 + 1, w3 = (nw + 2 - 3) / 2 + 1;
         // act_postprocess (dpt_block.py:353-405)
+        // 1x1 adapters: in fh2 mode a split pass + the fh2 GEMM (5x the exact-fp32 MFMA kernel's rate) instead of a3r_linear
+        auto adapter = [&](const float* t, int K, const float* w, const float* b, float* y, int N) {
+            if (!P.fh2()) { P.linear_f32(t, K, w, y, N, BN, N, K, P.epi(A3R_EPI_NONE, b)); return; }
+            const size_t keep = ar.off;
+            float* t2 = P.gin_scratch(BN, K);
+            P.linear(P.gin_from(t, t2, BN, K), K, w, y, N, BN, N, K, P.epi(A3R_EPI_NONE, b));
+            ar.off = keep;                                          // the split is dead once the GEMM is enqueued (stream order)
+        };
         float* a0 = ar.alloc((size_t)BN * ld[0]);
-        P.linear_f32(t0, E, Hd.a0w, a0, ld[0], BN, ld[0], E, P.epi(A3R_EPI_NONE, Hd.a0b));
+        adapter(t0, E, Hd.a0w, Hd.a0b, a0, ld[0]);
         float* l0 = ar.alloc((size_t)BN * 16 * ld[0]);
         {
             a3r_epilogue e = P.epi(A3R_EPI_PIXSHUF, Hd.a0tb);
@@ -903,7 +917,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             P.linear_f32(a0, ld[0], Hd.a0tw, l0, ld[0], BN, 16 * ld[0], ld[0], e);
         }
         float* a1 = ar.alloc((size_t)BN * ld[1]);
-        P.linear_f32(t1, D, Hd.a1w, a1, ld[1], BN, ld[1], D, P.epi(A3R_EPI_NONE, Hd.a1b));
+        adapter(t1, D, Hd.a1w, Hd.a1b, a1, ld[1]);
         float* l1 = ar.alloc((size_t)BN * 4 * ld[1]);
         {
             a3r_epilogue e = P.epi(A3R_EPI_PIXSHUF, Hd.a1tb);
@@ -911,9 +925,9 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             P.linear_f32(a1, ld[1], Hd.a1tw, l1, ld[1], BN, 4 * ld[1], ld[1], e);
         }
         float* l2 = ar.alloc((size_t)BN * ld[2]);
-        P.linear_f32(t2, D, Hd.a2w, l2, ld[2], BN, ld[2], D, P.epi(A3R_EPI_NONE, Hd.a2b));
+        adapter(t2, D, Hd.a2w, Hd.a2b, l2, ld[2]);
         float* a3 = ar.alloc((size_t)BN * ld[3]);
-        P.linear_f32(t3, D, Hd.a3w, a3, ld[3], BN, ld[3], D, P.epi(A3R_EPI_NONE, Hd.a3b));
+        adapter(t3, D, Hd.a3w, Hd.a3b, a3, ld[3]);
         float* l3 = P.map_alloc((size_t)B * h3 * w3, ld[3]);          // only feeds layer4_rn's conv: bf3 in bf3 mode
         if (!P.bf3()) {
             P.conv(a3, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, P.epi(A3R_EPI_NONE, Hd.a3cb));
