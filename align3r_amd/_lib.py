@@ -21,7 +21,7 @@ class Epilogue(C.Structure):
                 ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
                 ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int),
-                ("out_fh2", C.c_int), ("aux_fh2", c_void)]
+                ("out_fh2", C.c_int), ("aux_fh2", c_void), ("x_scale", C.c_float), ("out_scale", C.c_float), ("out_absmax", c_void)]
 
 
 class GroupPtrs(C.Structure):
@@ -29,7 +29,12 @@ class GroupPtrs(C.Structure):
 
 
 class GroupPtrsFh2(C.Structure):
-    _fields_ = [("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("w_scale", C.c_float)]
+    _fields_ = [("x", c_void), ("w", c_void), ("y", c_void), ("bias", c_void), ("resid", c_void), ("resid2", c_void), ("w_scale", C.c_float),
+                ("x_scale", C.c_float), ("out_scale", C.c_float), ("out_absmax", c_void)]
+
+
+class Fh2AttnRange(C.Structure):
+    _fields_ = [("q_scale", C.c_float), ("k_scale", C.c_float), ("v_scale", C.c_float), ("out_scale", C.c_float), ("out_absmax", c_void)]
 
 
 class ModelConfigC(C.Structure):
@@ -78,13 +83,13 @@ SIGNATURES = {
     "a3r_umeyama_chunks": (C.c_int, [C.c_int]),
     "a3r_umeyama_moments": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
     "a3r_fh2_bytes": (C.c_size_t, [C.c_long, C.c_int]),
-    "a3r_split_fh2": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, C.c_float, c_void]),
+    "a3r_split_fh2": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, C.c_float, c_void, c_void]),
     "a3r_absmax": (C.c_int, [c_void, C.c_long, c_void, c_void]),
     "a3r_fh2_weight_scale": (C.c_float, [C.c_float]),
-    "a3r_layernorm_fh2": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void]),
+    "a3r_layernorm_fh2": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, C.c_float, c_void, c_void]),
     "a3r_linear_fh2_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_linear_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
-    "a3r_attention_fh2": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_attention_fh2": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Fh2AttnRange), c_void]),
     "a3r_attention_bf3_fh2out": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_bf3_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "a3r_bf3_set_products": (C.c_int, [C.c_int]),
@@ -109,7 +114,7 @@ SIGNATURES = {
     "a3r_pnp_chunks": (C.c_int, [C.c_int]),
     "a3r_pnp_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "a3r_pnp_solve": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
-    "a3r_upsample2x_fh2": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "a3r_upsample2x_fh2": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_void, c_void]),
     "a3r_conv3x3_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_head_final": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_long, C.c_int, c_void]),
     "a3r_model_create": (C.c_int, [C.POINTER(ModelConfigC), C.POINTER(c_void)]),
@@ -123,6 +128,9 @@ SIGNATURES = {
     "a3r_model_encode": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, c_void]),
     "a3r_model_decode": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
     "a3r_model_tap": (C.c_int, [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_size_t)]),
+    "a3r_model_range_check": (C.c_int, [c_void, c_void, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "a3r_model_reset_ranges": (C.c_int, [c_void]),
+    "a3r_model_range_scales": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.POINTER(C.c_int)]),
     "a3r_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "a3r_align_create": (C.c_int, [C.POINTER(AlignDesc), C.POINTER(c_void), c_void]),
     "a3r_align_destroy": (C.c_int, [c_void]),

@@ -13,6 +13,7 @@
 // 53 KB per workgroup, so THREE workgroups of 4 waves share a CU.
 #include "common.h"
 #include "fh2.h"
+#include <cmath>
 
 namespace a3r {
 
@@ -35,6 +36,9 @@ struct Attn4Args {
     char* o;
     size_t pq, pk, pv, po;                  // row pitches in bytes (4 x leading dimension)
     int B, H, Nq, Nk;
+    float scale_log2e;                      // hd^-0.5 log2(e) / (q_scale k_scale): the exp2 argument's factor on the raw scores
+    float out_mul;                          // out_scale / v_scale, applied with the softmax normaliser
+    unsigned* out_absmax;                   // range statistics of the stored output (fh2.h), or null
 };
 
 typedef const __attribute__((address_space(1))) void* a4_gptr;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
 #pragma unroll
         for (int e = 0; e < 16; e++) oacc[i][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const float SCALE_LOG2E = 0.125f * 1.4426950408889634f;     // hd^-0.5 folded into the exp2 argument
+    const float SCALE_LOG2E = a.scale_log2e;                    // hd^-0.5 (and the operands' power-of-two scales) folded into the exp2 argument
 
     const int kfrag = qi * A4_KROW + half * 32;       // this lane's K operand: row qi (+32 kb), units (2 st + half) 2 + p
     const int vfrag = qi * A4_VROW + half * 16;       // this lane's V^T operand: row d = qi (+32 db), unit 4 kb + 2 s2 + half
@@ -211,7 +215,8 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.f / l_tot;                          // P and l both carry the factor 2^10: it cancels
+    const float inv_l = a.out_mul / l_tot;                    // P and l both carry the factor 2^10: it cancels
+    float amax = 0.f;
     if (q_row < a.Nq) {
         // lane (query, half) holds d = 32 db + 8 g + 4 half + (0..3): half of each plane's unit
         char* op = a.o + ((size_t)b * a.Nq + q_row) * a.po;
@@ -221,17 +226,25 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
             for (int g = 0; g < 4; g++) {
                 const f32x4 v = {oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l, oacc[db][4 * g + 2] * inv_l,
                                  oacc[db][4 * g + 3] * inv_l};
+                amax = fh2_amax4(amax, v);
                 fh2_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v);
             }
     }
+    fh2_publish_absmax(a.out_absmax, amax);
 }
 
 }  // namespace a3r
 using namespace a3r;
 
 extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ldk, const void* v2, int ldv, void* o2, int ldo,
-                                 int B, int H, int Nq, int Nk, void* stream) {
+                                 int B, int H, int Nq, int Nk, const a3r_fh2_attn_range* range, void* stream) {
     A3R_CHECK_ARG(q2 && k2 && v2 && o2, "a3r_attention_fh2: null pointer");
+    a3r_fh2_attn_range r = range ? *range : a3r_fh2_attn_range{};
+    float* rs[4] = {&r.q_scale, &r.k_scale, &r.v_scale, &r.out_scale};
+    for (float* p : rs) {
+        if (*p == 0.f) *p = 1.f;
+        A3R_CHECK_ARG(*p > 0.f && std::isfinite(*p), "a3r_attention_fh2: scales must be positive and finite");
+    }
     A3R_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "a3r_attention_fh2: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     A3R_CHECK_ARG(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ldo >= H * 64, "a3r_attention_fh2: row strides < H*64");
     A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_fh2: row strides must be multiples of 8");
@@ -242,7 +255,8 @@ extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ld
         A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES));
     }
     Attn4Args a = {static_cast<const char*>(q2), static_cast<const char*>(k2), static_cast<const char*>(v2), static_cast<char*>(o2),
-                   (size_t)ldq * 4, (size_t)ldk * 4, (size_t)ldv * 4, (size_t)ldo * 4, B, H, Nq, Nk};
+                   (size_t)ldq * 4, (size_t)ldk * 4, (size_t)ldv * 4, (size_t)ldo * 4, B, H, Nq, Nk,
+                   0.125f * 1.4426950408889634f / (r.q_scale * r.k_scale), r.out_scale / r.v_scale, r.out_absmax};
     const int nqb = (Nq + A4Q - 1) / A4Q, groups = B * H;
     dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION_FH2, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));

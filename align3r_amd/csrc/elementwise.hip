@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void layernorm_pair_kernel(const float* __rest
 // two planes' 16-byte units of its group -- 32 contiguous bytes per lane, 2 KB contiguous per wave and step.
 template <int VPL>   // 8-k groups per lane: D <= 512 VPL (D % 8 == 0); a lane whose group lies past the row contributes zeros and stores nothing
 __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps) {
+                                                             const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps,
+                                                             float scale, unsigned* __restrict__ absmax) {
 #pragma clang fp contract(off)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restr
     const f32x4* wr = reinterpret_cast<const f32x4*>(w);
     const f32x4* br = reinterpret_cast<const f32x4*>(b);
     char* yr = y2 + (size_t)row * fh2_row_bytes(D);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         if (lane + 64 * i >= G) continue;
@@ -157,14 +159,17 @@ __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restr
             const int c = 2 * (lane + 64 * i) + h;
             const f32x4 t = v[i][h] * rstd, wv = wr[c], bv = br[c];
             o[h] = f32x4{__builtin_fmaf(t.x, wv.x, bv.x), __builtin_fmaf(t.y, wv.y, bv.y), __builtin_fmaf(t.z, wv.z, bv.z),
-                         __builtin_fmaf(t.w, wv.w, bv.w)};
+                         __builtin_fmaf(t.w, wv.w, bv.w)} * scale;
+            amax = fh2_amax4(amax, o[h]);
         }
         fh2_store8(yr, (lane + 64 * i) * 8, o[0], o[1]);
     }
+    fh2_publish_absmax(absmax, amax);                          // (rows are per wave: every lane of a live wave arrives here)
 }
 // any D % 32 == 0: lanes stride over the row's 8-k groups (three passes over an L1/L2-resident row)
 __global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                     const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps) {
+                                                                     const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps,
+                                                                     float scale, unsigned* __restrict__ absmax) {
 #pragma clang fp contract(off)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -176,12 +181,15 @@ __global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float*
     for (int i = lane; i < D; i += 64) { const float c = xr[i] - mean; ss += c * c; }
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
     char* yr = y2 + (size_t)row * fh2_row_bytes(D);
+    float amax = 0.f;
     for (int k0 = lane * 8; k0 < D; k0 += 512) {
         f32x4 o[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j >> 2][j & 3] = __builtin_fmaf((xr[k0 + j] - mean) * rstd, w[k0 + j], b[k0 + j]);
+        for (int j = 0; j < 8; j++) o[j >> 2][j & 3] = __builtin_fmaf((xr[k0 + j] - mean) * rstd, w[k0 + j], b[k0 + j]) * scale;
+        amax = fh2_amax4(fh2_amax4(amax, o[0]), o[1]);
         fh2_store8(yr, k0, o[0], o[1]);
     }
+    fh2_publish_absmax(absmax, amax);
 }
 
 // generic fallback (any D % 4 == 0; D % 8 == 0 for BF3): one wave per row, three passes over an L1/L2-resident row
@@ -271,7 +279,7 @@ __device__ __forceinline__ f32x4 bilerp4(f32x4 v00, f32x4 v01, f32x4 v10, f32x4 
 // 4-channel fh2 form VALU-bound at 150 instructions per thread).
 template <int FMT>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
-                                                         int Hc, int Wc) {
+                                                         int Hc, int Wc, float scale, unsigned* __restrict__ absmax) {
     constexpr int Q = FMT == 2 ? 2 : 1;                        // float4 per thread
     const float sh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float sw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
@@ -280,13 +288,15 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const unsigned CG = (unsigned)C4 / Q;                      // channel groups per pixel
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     const unsigned ox = idx / CG, c = (idx - ox * CG) * Q;     // c: first float4 of this thread
-    if (ox >= (unsigned)Wc) return;
+    const bool live = ox < (unsigned)Wc;                     // (no early return in the fh2 form: the range statistics need every lane at the end)
+    if (FMT != 2 && !live) return;
     const float fx = sw * (float)ox;
     int x0 = (int)fx;
     x0 = x0 < W - 1 ? x0 : W - 1;
     const int x1 = x0 < W - 1 ? x0 + 1 : x0;
     const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-    for (int row = blockIdx.y; row < B * Hc; row += gridDim.y) {   // (batch, output row): uniform per workgroup
+    float amax = 0.f;
+    for (int row = blockIdx.y; live && row < B * Hc; row += gridDim.y) {   // (batch, output row): uniform per workgroup
         const int b = row / Hc, oy = row - b * Hc;
         const float fy = sh * (float)oy;
         int y0 = (int)fy;
@@ -302,9 +312,13 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
             o[q] = bilerp4(r0[(long)x0 * C4 + q], r0[(long)x1 * C4 + q], r1[(long)x0 * C4 + q], r1[(long)x1 * C4 + q], lx0, lx1, ly0, ly1);
         const long pix = (long)row * Wc + ox;
         if (FMT == 1) bf3_store4(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 24), c * 4, o[0]);
-        else if (FMT == 2) fh2_store8(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 16), c * 4, o[0], o[Q - 1]);
-        else yv[pix * C4 + c] = o[0];
+        else if (FMT == 2) {
+            const f32x4 lo = o[0] * scale, hi = o[Q - 1] * scale;
+            amax = fh2_amax4(fh2_amax4(amax, lo), hi);
+            fh2_store8(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 16), c * 4, lo, hi);
+        } else yv[pix * C4 + c] = o[0];
     }
+    if (FMT == 2) fh2_publish_absmax(absmax, amax);
 }
 
 // ------------------------------------------------------------------------------------------- head final
@@ -514,8 +528,10 @@ extern "C" int a3r_layernorm(const float* x, const float* w, const float* b, flo
     return launch_layernorm<false>(x, w, b, y, M, D, eps, stream);
 }
 
-extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b, void* y2, int M, int D, float eps, void* stream) {
+extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b, void* y2, int M, int D, float eps, float scale,
+                                 unsigned* absmax, void* stream) {
     A3R_CHECK_ARG(x && w && b && y2, "a3r_layernorm_fh2: null pointer");
+    A3R_CHECK_ARG(scale > 0.f && std::isfinite(scale), "a3r_layernorm_fh2: scale must be positive and finite");
     A3R_CHECK_ARG(M > 0 && D > 0 && D % 32 == 0, "a3r_layernorm_fh2: bad shape M=%d D=%d (D must be a multiple of 32)", M, D);
     A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(y2) & 15) == 0, "a3r_layernorm_fh2: y2 must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
@@ -525,10 +541,10 @@ extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b,
     // rows up to 1536 wide stay in registers (one, two or three 8-k groups per lane; D = 768 uses two with the upper lanes idle in
     // the second: 2.7 -> 4.5+ TB/s against the three-pass generic kernel it used before)
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
-    if (aligned && D <= 512) hipLaunchKernelGGL(layernorm_fh2_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (aligned && D <= 1024) hipLaunchKernelGGL(layernorm_fh2_kernel<2>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else if (aligned && D <= 1536) hipLaunchKernelGGL(layernorm_fh2_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps);
-    else hipLaunchKernelGGL(layernorm_fh2_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps);
+    if (aligned && D <= 512) hipLaunchKernelGGL(layernorm_fh2_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
+    else if (aligned && D <= 1024) hipLaunchKernelGGL(layernorm_fh2_kernel<2>, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
+    else if (aligned && D <= 1536) hipLaunchKernelGGL(layernorm_fh2_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
+    else hipLaunchKernelGGL(layernorm_fh2_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -595,7 +611,7 @@ extern "C" int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<0>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc);
+    hipLaunchKernelGGL(upsample2x_kernel<0>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, y, B, H, W, C / 4, Hc, Wc, 1.f, nullptr);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -607,19 +623,21 @@ extern "C" int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W,
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 24.0 * total + 4.0 * B * H * W * C, as_stream(stream));
     hipLaunchKernelGGL(upsample2x_kernel<1>, upsample_grid(B, Hc, Wc, C / 4), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y3), B, H, W,
-                       C / 4, Hc, Wc);
+                       C / 4, Hc, Wc, 1.f, nullptr);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
 
-extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W, int C, int Hc, int Wc, void* stream) {
+extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W, int C, int Hc, int Wc, float scale, unsigned* absmax,
+                                  void* stream) {
     A3R_CHECK_ARG(x && y2, "a3r_upsample2x_fh2: null pointer");
+    A3R_CHECK_ARG(scale > 0.f && std::isfinite(scale), "a3r_upsample2x_fh2: scale must be positive and finite");
     A3R_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "a3r_upsample2x_fh2: bad shape (C must be a multiple of 8)");
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_fh2: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
     hipLaunchKernelGGL(upsample2x_kernel<2>, upsample_grid(B, Hc, Wc, C / 8), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
-                       C / 4, Hc, Wc);
+                       C / 4, Hc, Wc, scale, absmax);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }

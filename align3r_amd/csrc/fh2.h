@@ -8,6 +8,12 @@
 // the reference's own fp32 GEMM has: measured against float64 the result is as accurate as the exact-fp32 MFMA kernel's
 // (tests/test_gpu_fh2.py: max |err| / sum|a||b| within 1.2x of a3r_linear's), at half the matrix passes and two thirds of the
 // operand bytes of the exact three-plane bf16 form (bf3.h), which stays available (A3R_GEMM=bf3).
+// RANGE.  fp16 ends at 65504 and h1 turns subnormal where |s x| < 2^-3, so an fh2 tensor is only fp32-grade while its largest |s x| stays
+// inside [2^-2, 2^15].  Weights get their s once from max|w|.  Activations start at s = 1; every kernel that WRITES an fh2 tensor takes
+// the power of two to store it with and a device word that receives max |s x| (atomic max on the bit pattern), every kernel that READS
+// one takes the s it was stored with and divides it out exactly.  The model plan (model.hip) keeps one s per producing site and
+// a3r_model_range_check() moves the sites whose maximum left the band -- an out-of-range checkpoint costs one repeated forward, not a
+// wrong or refused result.
 // Memory layout of a [R, K] matrix (K % 32 == 0): [R][K/8][2][8] fp16 -- per row and group of 8 consecutive k the two planes'
 // 16-byte pieces are adjacent (32 bytes); row pitch 4 K bytes; the 32 k of one GEMM stage are exactly one 128-byte line.
 #pragma once
@@ -56,6 +62,20 @@ __device__ __forceinline__ void fh2_store4(char* row, int k0, f32x4 v) {
     typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2_*>(d) = u32x2_{a0, b0};
     *reinterpret_cast<u32x2_*>(d + 16) = u32x2_{a1, b1};
+}
+
+// ---- range statistics: running max |v| (v_max3_f32 with |.| source modifiers: half an instruction per element)
+__device__ __forceinline__ float fh2_amax2(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
+__device__ __forceinline__ float fh2_amax4(float m, f32x4 v) { return fh2_amax2(fh2_amax2(m, v.x, v.y), v.z, v.w); }
+// wave-wide max of m -> *slot (a non-negative float compared as an unsigned integer; Inf sorts above every finite value).  Call with
+// every lane of the wave active.  The plain read first: once the maximum is in, almost no wave issues the atomic.
+__device__ __forceinline__ void fh2_publish_absmax(unsigned* slot, float m) {
+    if (!slot) return;                                   // wave-uniform
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __float_as_uint(m);
+        if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+    }
 }
 
 }  // namespace a3r

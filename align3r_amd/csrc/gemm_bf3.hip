@@ -255,8 +255,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf3_kernel(GemmArgs g) {
         if (TN == 2 && epilogue16_lds_ok(g, P)) {                 // wave-uniform
             __syncthreads();                                       // every wave is done reading the last stage
             if constexpr (TN == 2)
+            {
+                float amax_unused = 0.f;                           // (range statistics exist on the fh2 kernels only)
                 gemm_epilogue16_lds<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane,
-                                                  reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)));
+                                                  reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)), &amax_unused);
+            }
         } else {
             gemm_epilogue16<TM, TN, FULL>(g, P, acc, m0, n0, wm * WTM, wn * WTN, lane);
         }

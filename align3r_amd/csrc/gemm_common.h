@@ -14,6 +14,9 @@ struct GroupPtrs {
     const float* bias;
     const float* resid;
     const float* resid2;
+    // fh2 kernels: the power of two the out_fh2 / aux_fh2 output is stored with, and the word receiving max |out_scale * value| (or null)
+    float out_scale;
+    unsigned* out_absmax;
 };
 
 struct GemmArgs {
@@ -226,7 +229,7 @@ constexpr int epi_lds_wave_bytes(int wtm) { return wtm * EPI_LDS_PITCH * 4 > 32 
 
 template <int TM, int TN, bool FULL, int EPI, int O3>
 __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
-                                                         int wrow0, int wcol0, int lane, float* lds) {
+                                                         int wrow0, int wcol0, int lane, float* lds, float* amax) {
     static_assert(TN == 2, "wave tiles 32 columns wide");
     constexpr int WTM = TM * 16, WTN = TN * 16, LPR = WTN / 4, RPI = 64 / LPR, ITERS = WTM / RPI;      // lanes per row, rows per pass
     const a3r_epilogue& ep = g.epi;
@@ -357,7 +360,11 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
         if (out3 || out2) {
             if (relu3) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (out3) bf3_store4(out3 + bf3_row_offset(grow, g.N, 0), gcol, v, 0);
-            else fh2_store4(out2 + (size_t)grow * fh2_row_bytes(g.N), gcol, v);
+            else {
+                v = v * P.out_scale;                              // fh2 kernels only (their launch code sets out_scale >= 2^-60)
+                *amax = fh2_amax4(*amax, v);
+                fh2_store4(out2 + (size_t)grow * fh2_row_bytes(g.N), gcol, v);
+            }
         }
     }
 }
@@ -374,10 +381,10 @@ __device__ __forceinline__ bool epilogue16_lds_ok(const GemmArgs& g, const Group
 
 template <int TM, int TN, bool FULL>
 __device__ __forceinline__ void gemm_epilogue16_lds(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][TN], int m0, int n0,
-                                                    int wrow0, int wcol0, int lane, float* lds) {
+                                                    int wrow0, int wcol0, int lane, float* lds, float* amax) {
     const a3r_epilogue& ep = g.epi;
     const bool has3 = ep.out_bf3 || ep.aux_bf3;
-#define A3R_EPI_LDS(E, O) gemm_epilogue16_lds_body<TM, TN, FULL, E, O>(g, P, acc, m0, n0, wrow0, wcol0, lane, lds)
+#define A3R_EPI_LDS(E, O) gemm_epilogue16_lds_body<TM, TN, FULL, E, O>(g, P, acc, m0, n0, wrow0, wcol0, lane, lds, amax)
     if (!has3) {
         if (ep.epi == A3R_EPI_RESID) A3R_EPI_LDS(A3R_EPI_RESID, 0);
         else if (ep.epi == A3R_EPI_NONE) A3R_EPI_LDS(A3R_EPI_NONE, 0);
@@ -393,8 +400,9 @@ __device__ __forceinline__ void gemm_epilogue16_lds(const GemmArgs& g, const Gro
 #undef A3R_EPI_LDS
 }
 
-static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who, bool bf3_kernel = false) {
+static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char* who, bool bf3_kernel = false, bool fh2_kernel = false) {
     if (!e) return A3R_OK;
+    A3R_CHECK_ARG(fh2_kernel || (!e->out_fh2 && !e->aux_fh2), "%s: out_fh2 / aux_fh2 are only available on the fh2 kernels", who);
     if (e->out_bf3) {
         A3R_CHECK_ARG(bf3_kernel, "%s: out_bf3 is only available on the bf3 kernels", who);
         A3R_CHECK_ARG(N % 8 == 0 && (e->epi == A3R_EPI_NONE || e->epi == A3R_EPI_GELU || e->epi == A3R_EPI_RELU || e->epi == A3R_EPI_ROPE),

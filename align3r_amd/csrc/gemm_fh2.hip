@@ -36,7 +36,7 @@ __device__ __forceinline__ void fh2_wait_vmcnt_dyn(int n) {
 
 struct Fh2Args {
     GemmArgs g;
-    float inv_wscale[4];      // per group: 1 / (power-of-two scale the weights were stored with)
+    float inv_wscale[4];      // per group: 1 / (w_scale x_scale), times out_scale for an out_fh2 output whose epilogue is homogeneous (not GELU)
     int gm;                   // row tiles per L2 block: workgroup ids walk gm row tiles before the next column tile (1 = row-major tile order)
     int lab;                  // developer experiment (A3R_FH2_LAB): 1 = every tile LOADS operand tiles (m & 1, n & 1) -- all L2 hits
 };
@@ -64,7 +64,7 @@ constexpr int EPI_FH2_WAVE_BYTES = 32 * EPI_FH2_PITCH;   // 4608
 // keeps the compiler from packing the arithmetic of neighbouring elements)
 template <int TM, bool FULL, int EPI>
 __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int n0, int wrow0,
-                                                      int wcol0, int lane, char* img) {
+                                                      int wcol0, int lane, char* img, float& amax) {
     static_assert(TM % 2 == 0, "halves of 32 rows");
     const a3r_epilogue& ep = g.epi;
     const int quad = lane >> 4, lcol = lane & 15;
@@ -73,6 +73,9 @@ __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const G
     const int kcol0 = n0 + wcol0;                            // a multiple of 32: one whole 128-byte k block of the output rows
     const float inv_tokens = EPI == A3R_EPI_ROPE ? 1.f / (float)ep.tokens_per_image : 0.f;
     const float inv_gw = EPI == A3R_EPI_ROPE ? 1.f / (float)ep.grid_w : 0.f;
+    // the output is stored as out_scale * value (fh2.h, RANGE).  Bias, ReLU and the RoPE rotation are homogeneous: there the launch
+    // code folded out_scale into the accumulator's factor and only the bias is multiplied here; GELU is not: one more product.
+    const float bscale = EPI == A3R_EPI_GELU ? 1.f : P.out_scale;
 #pragma unroll
     for (int half = 0; half < TM / 2; half++) {
 #pragma unroll
@@ -80,11 +83,11 @@ __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const G
             const int colbase = n0 + wcol0 + j * 16;
             const int col = colbase + lcol;
             const bool col_ok = FULL || col < g.N;
-            const float bias = (P.bias && col_ok) ? P.bias[col] : 0.f;
+            const float bias = (P.bias && col_ok) ? P.bias[col] * bscale : 0.f;
             // 2-D RoPE on the leading rope_cols columns (pairs (d, d + 16) inside each 32-wide half of a head, pos_embed.py:130-157):
             // the partner column is accumulator tile j ^ 1 of the same lane
             const bool do_rope = EPI == A3R_EPI_ROPE && colbase < ep.rope_cols;          // wave-uniform (rope_cols % 64 == 0)
-            const float bias_o = (do_rope && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] : 0.f;
+            const float bias_o = (do_rope && P.bias) ? P.bias[min(col ^ 16, g.N - 1)] * bscale : 0.f;
             const bool rope_x = (colbase & 32) != 0, second = (colbase & 16) != 0;
             // a lane holds one column of four rows; the fh2 form packs neighbouring COLUMNS.  Neighbouring lanes (columns c, c + 1)
             // trade half of their rows by DPP: the even lane ends up with rows e = 0, 1 of both columns, the odd lane with rows 2, 3,
@@ -114,9 +117,10 @@ __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const G
                         const float t = __fmul_rn(other, sn);
                         v[e] = __fmaf_rn(v[e], c, second ? t : -t);
                     }
-                    if (EPI == A3R_EPI_GELU) v[e] = gelu_erf(v[e]);
+                    if (EPI == A3R_EPI_GELU) v[e] = gelu_erf(v[e]) * P.out_scale;
                     else if (EPI == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                 }
+                amax = fh2_amax2(fh2_amax2(amax, v[0], v[1]), v[2], v[3]);
                 // send the rows the neighbour keeps, receive its values of the rows this lane keeps
                 const float g0 = dpp_xor1(odd ? v[0] : v[2]), g1 = dpp_xor1(odd ? v[1] : v[3]);
                 const float l0 = odd ? g0 : v[0], r0 = odd ? v[2] : g0;       // kept row 0: (column c, column c + 1)
@@ -148,12 +152,12 @@ __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const G
 
 template <int TM, bool FULL>
 __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int n0, int wrow0,
-                                                 int wcol0, int lane, char* img) {
+                                                 int wcol0, int lane, char* img, float& amax) {
     switch (g.epi.epi) {                                           // wave-uniform
-        case A3R_EPI_GELU: fh2_epilogue_out_body<TM, FULL, A3R_EPI_GELU>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
-        case A3R_EPI_RELU: fh2_epilogue_out_body<TM, FULL, A3R_EPI_RELU>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
-        case A3R_EPI_ROPE: fh2_epilogue_out_body<TM, FULL, A3R_EPI_ROPE>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
-        default: fh2_epilogue_out_body<TM, FULL, A3R_EPI_NONE>(g, P, acc, m0, n0, wrow0, wcol0, lane, img); break;
+        case A3R_EPI_GELU: fh2_epilogue_out_body<TM, FULL, A3R_EPI_GELU>(g, P, acc, m0, n0, wrow0, wcol0, lane, img, amax); break;
+        case A3R_EPI_RELU: fh2_epilogue_out_body<TM, FULL, A3R_EPI_RELU>(g, P, acc, m0, n0, wrow0, wcol0, lane, img, amax); break;
+        case A3R_EPI_ROPE: fh2_epilogue_out_body<TM, FULL, A3R_EPI_ROPE>(g, P, acc, m0, n0, wrow0, wcol0, lane, img, amax); break;
+        default: fh2_epilogue_out_body<TM, FULL, A3R_EPI_NONE>(g, P, acc, m0, n0, wrow0, wcol0, lane, img, amax); break;
     }
 }
 
@@ -342,8 +346,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     } else {
         kstep(kt, bfr[0], bfr[1], std::false_type{});
     }
-    // undo the weight scale (an exact power of two), then the shared epilogues
+    // undo the operand scales (exact powers of two; times the output scale where the epilogue is homogeneous), then the epilogues
     const float inv = fa.inv_wscale[grp];
+    float amax = 0.f;                                          // max |stored fh2 value| of this wave (range statistics, fh2.h)
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -358,26 +363,32 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
 #pragma unroll
         for (int i = 0; i < TM; i++) { blk[i][0] = acc[i][2 * cb]; blk[i][1] = acc[i][2 * cb + 1]; }
         const int wcol = wn * WTN + cb * 32;
-        if (to_fh2) fh2_epilogue_out<TM, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane, smem + wave * EPI_FH2_WAVE_BYTES);
+        if (to_fh2) fh2_epilogue_out<TM, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane, smem + wave * EPI_FH2_WAVE_BYTES, amax);
         else if (via_lds)
-            gemm_epilogue16_lds<TM, 2, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane, reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)));
+            gemm_epilogue16_lds<TM, 2, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane, reinterpret_cast<float*>(smem + wave * epi_lds_wave_bytes(WTM)), &amax);
         else gemm_epilogue16<TM, 2, FULL>(g, P, blk, m0, n0, wm * WTM, wcol, lane);
     };
     block(std::integral_constant<int, 0>{});
     if constexpr (TN >= 4) block(std::integral_constant<int, 1>{});
     if constexpr (TN >= 6) block(std::integral_constant<int, 2>{});
     if constexpr (TN >= 8) block(std::integral_constant<int, 3>{});
+    fh2_publish_absmax(P.out_absmax, amax);
 }
 
 // fp32 [M, ldx] -> fh2 [M][K/8][2][8]: one thread per group of 8 consecutive k (32 B in, 32 contiguous bytes out)
-__global__ __launch_bounds__(256) void split_fh2_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8, float scale) {
+__global__ __launch_bounds__(256) void split_fh2_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8, float scale,
+                                                        unsigned* __restrict__ absmax) {
     const long total = M * K8;
+    float amax = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long row = i / K8;
         const int kg = (int)(i - row * K8);
         const f32x4* src = reinterpret_cast<const f32x4*>(x + row * ldx + kg * 8);
-        fh2_store8(y + row * ((size_t)K8 * 32), kg * 8, src[0] * scale, src[1] * scale);
+        const f32x4 lo = src[0] * scale, hi = src[1] * scale;
+        amax = fh2_amax4(fh2_amax4(amax, lo), hi);
+        fh2_store8(y + row * ((size_t)K8 * 32), kg * 8, lo, hi);
     }
+    fh2_publish_absmax(absmax, amax);                       // every lane arrives here
 }
 
 // max |x| of n floats -> *out (a non-negative float compared as an unsigned integer; *out must be zero before the launch)
@@ -469,12 +480,28 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     return A3R_EINVAL;
 }
 
+// operand / output scales of one problem: 0 means 1; they must be finite and positive (powers of two by contract: only then is
+// dividing them out exact)
+static int fh2_scales(float x_scale, float out_scale, const char* who, float* xs, float* os) {
+    *xs = x_scale == 0.f ? 1.f : x_scale;
+    *os = out_scale == 0.f ? 1.f : out_scale;
+    A3R_CHECK_ARG(*xs > 0.f && std::isfinite(*xs) && *os > 0.f && std::isfinite(*os), "%s: x_scale / out_scale must be positive and finite", who);
+    return A3R_OK;
+}
+// the factor the accumulator is multiplied with: 1 / (w_scale x_scale), times out_scale when the whole epilogue of an out_fh2
+// output is homogeneous of degree one (bias -- scaled in the kernel --, ReLU, RoPE); GELU is scaled after the activation, and an
+// fp32 y with an aux_fh2 twin scales the twin alone
+static float fh2_acc_factor(const a3r_epilogue& e, float w_scale, float xs, float os) {
+    const float pre = (e.out_fh2 && e.epi != A3R_EPI_GELU) ? os : 1.f;
+    return pre / (w_scale * xs);
+}
+
 }  // namespace a3r
 using namespace a3r;
 
 extern "C" size_t a3r_fh2_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)rows * K * 4 : 0; }
 
-extern "C" int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, void* stream) {
+extern "C" int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, unsigned* absmax, void* stream) {
     A3R_CHECK_ARG(x && y, "a3r_split_fh2: null pointer");
     A3R_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0, "a3r_split_fh2: K (%d) must be a positive multiple of 8 (M=%ld)", K, M);
     A3R_CHECK_ARG(ldx >= K && ldx % 4 == 0, "a3r_split_fh2: bad leading dimension %d", ldx);
@@ -485,7 +512,7 @@ extern "C" int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, fl
     ProfScope prof(PK_SPLIT, 8.0 * M * K, st);
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(split_fh2_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, st, x, ldx,
-                       static_cast<char*>(y), M, K / 8, scale);
+                       static_cast<char*>(y), M, K / 8, scale, absmax);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }
@@ -514,7 +541,7 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
     A3R_CHECK_ARG(M > 0 && N > 0 && K > 0, "a3r_linear_fh2: M, N, K must be positive (got %d, %d, %d)", M, N, K);
     A3R_CHECK_ARG(K % 32 == 0, "a3r_linear_fh2: K (%d) must be a multiple of 32", K);
     A3R_CHECK_ARG(ldc >= 1, "a3r_linear_fh2: bad leading dimension ldc=%d", ldc);
-    if (int rc = check_epilogue(epi, M, N, "a3r_linear_fh2", true)) return rc;
+    if (int rc = check_epilogue(epi, M, N, "a3r_linear_fh2", true, true)) return rc;
     Fh2Args fa = {};
     GemmArgs& g = fa.g;
     if (epi) g.epi = *epi;
@@ -532,11 +559,13 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
                       "a3r_linear_fh2: out_fh2 needs N %% 32 == 0, ldc == N and a NONE / GELU / RELU / ROPE epilogue");
     }
     for (int i = 0; i < n_groups; i++) {
+        float xs, os;
+        if (int rc = fh2_scales(groups[i].x_scale, groups[i].out_scale, "a3r_linear_fh2", &xs, &os)) return rc;
         g.grp[i] = {static_cast<const float*>(groups[i].x2), static_cast<const float*>(groups[i].w2), groups[i].y, groups[i].bias,
-                    groups[i].resid, groups[i].resid2};
+                    groups[i].resid, groups[i].resid2, os, groups[i].out_absmax};
         if (int rc = check_group(g.grp[i], g.epi.epi, "a3r_linear_fh2")) return rc;
         A3R_CHECK_ARG(groups[i].w_scale > 0.f, "a3r_linear_fh2: w_scale must be positive");
-        fa.inv_wscale[i] = 1.f / groups[i].w_scale;
+        fa.inv_wscale[i] = fh2_acc_factor(g.epi, groups[i].w_scale, xs, os);
     }
     g.groups = n_groups;
     g.lda = K; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
@@ -547,7 +576,8 @@ extern "C" int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_gr
 
 extern "C" int a3r_linear_fh2(const void* x2, const void* w2, float w_scale, float* y, int ldc, int M, int N, int K,
                               const a3r_epilogue* epi, void* stream) {
-    a3r_group_ptrs_fh2 p = {x2, w2, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr, w_scale};
+    a3r_group_ptrs_fh2 p = {x2, w2, y, epi ? epi->bias : nullptr, epi ? epi->resid : nullptr, epi ? epi->resid2 : nullptr, w_scale,
+                            epi ? epi->x_scale : 0.f, epi ? epi->out_scale : 0.f, epi ? epi->out_absmax : nullptr};
     return a3r_linear_fh2_grouped(&p, 1, ldc, M, N, K, epi, stream);
 }
 
@@ -561,7 +591,7 @@ extern "C" int a3r_conv3x3_fh2(const void* x2, const void* wp2, float w_scale, f
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long M = (long)B * Ho * Wo;
     A3R_CHECK_ARG(M < (1L << 31) && (long)B * H * W * Cin * 4 < (1L << 46), "a3r_conv3x3_fh2: map too large");
-    if (int rc = check_epilogue(epi, (int)M, Cout, "a3r_conv3x3_fh2", true)) return rc;
+    if (int rc = check_epilogue(epi, (int)M, Cout, "a3r_conv3x3_fh2", true, true)) return rc;
     Fh2Args fa = {};
     GemmArgs& g = fa.g;
     if (epi) g.epi = *epi;
@@ -573,9 +603,11 @@ extern "C" int a3r_conv3x3_fh2(const void* x2, const void* wp2, float w_scale, f
                       "a3r_conv3x3_fh2: out_fh2 needs Cout %% 32 == 0, a NONE / GELU / RELU epilogue and no aux_fh2");
     if (g.epi.aux_fh2)
         A3R_CHECK_ARG(Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(g.epi.aux_fh2) & 15) == 0, "a3r_conv3x3_fh2: aux_fh2 needs Cout %% 8 == 0 and a 16-byte aligned buffer");
-    g.grp[0] = {static_cast<const float*>(x2), static_cast<const float*>(wp2), y, g.epi.bias, g.epi.resid, g.epi.resid2};
+    float xs, os;
+    if (int rc = fh2_scales(g.epi.x_scale, g.epi.out_scale, "a3r_conv3x3_fh2", &xs, &os)) return rc;
+    g.grp[0] = {static_cast<const float*>(x2), static_cast<const float*>(wp2), y, g.epi.bias, g.epi.resid, g.epi.resid2, os, g.epi.out_absmax};
     if (int rc = check_group(g.grp[0], g.epi.epi, "a3r_conv3x3_fh2")) return rc;
-    fa.inv_wscale[0] = 1.f / w_scale;
+    fa.inv_wscale[0] = fh2_acc_factor(g.epi, w_scale, xs, os);
     g.groups = 1;
     g.M = (int)M; g.N = Cout; g.K = 9 * Cin; g.lda = g.K; g.ldc = Cout;
     g.cH = H; g.cW = W; g.cCin = Cin; g.cHo = Ho; g.cWo = Wo; g.cStride = stride;

@@ -15,6 +15,8 @@
 #include <vector>
 #include <new>
 #include <cstdlib>
+#include <cmath>
+#include <cstring>
 
 namespace a3r {
 
@@ -70,6 +72,12 @@ struct a3r_model_s {
     bool conv_fh2 = true;     // fh2 mode: the DPT maps / 3x3 convs on the fh2 kernel too (A3R_CONV=bf3 keeps them on the three-plane bf16 kernel)
     std::map<const float*, std::pair<const void*, float>> w2;
     static constexpr int MAX_POS = 256;
+    // fh2 range control (fh2.h, RANGE; a3r_model_range_check): one power-of-two scale per fh2-producing site of the launch plan, kept
+    // per plan phase (forward / encode / decode walk different plans), and the device words the sites record max |stored value| in
+    static constexpr int MAX_SITES = 1024;
+    std::vector<float> site_scale[3];
+    unsigned* stats = nullptr;       // [MAX_SITES], inside the packed buffer
+    int last_phase = -1, last_sites = 0;
 };
 
 static int n_pc_blocks(const a3r_model_config& c) { return c.dec_depth / 2 - 2; }
@@ -159,6 +167,8 @@ std::vector<PackItem> pack_plan(a3r_model_s* m, size_t* total) {
         }
     v.push_back({"rope", 3, 0, 0, 0, off});
     off = align_up(off + (size_t)2 * a3r_model_s::MAX_POS * 16 * 4, 256);
+    v.push_back({"range_stats", 6, 0, 0, 0, off});        // kind 6: the range statistics words of the fh2 sites
+    off = align_up(off + (size_t)a3r_model_s::MAX_SITES * 4, 256);
     if (m->use_bf3) {
         auto twin = [&](const std::string& n, int N, int K) {
             v.push_back({n, 4, N, K, 0, off});
@@ -276,6 +286,11 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
     for (const PackItem& it : plan) {
         float* dst = reinterpret_cast<float*>(pk + it.off);
         if (it.kind == 4 || it.kind == 5) continue;      // after binding (shapes are validated there)
+        if (it.kind == 6) {
+            m->stats = reinterpret_cast<unsigned*>(dst);
+            A3R_HIP(hipMemsetAsync(dst, 0, (size_t)a3r_model_s::MAX_SITES * 4, st));
+            continue;
+        }
         if (it.kind == 0) {
             const float* src;
             NEED(it.name, &src, it.a, it.b, 3, 3);
@@ -384,7 +399,7 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
             A3R_HIP(hipMemcpyAsync(&amax, scratch, 4, hipMemcpyDeviceToHost, st));
             A3R_HIP(hipStreamSynchronize(st));
             const float scale = a3r_fh2_weight_scale(amax);
-            if (int rc = a3r_split_fh2(src, it.b, dst, it.a, it.b, scale, stream)) return rc;
+            if (int rc = a3r_split_fh2(src, it.b, dst, it.a, it.b, scale, nullptr, stream)) return rc;
             m->w2[src] = {dst, scale};
         }
     }
@@ -403,6 +418,35 @@ struct Plan {
     bool trace = getenv("A3R_TRACE") != nullptr;   // debugging aid: name + synchronise every op
     int opno = 0;
     bool dry() const { return ar.dry; }
+    // ---- fh2 range control: every op that WRITES an fh2 tensor is a site (numbered in plan order) with its own power-of-two
+    // scale; the scale travels with the buffer pointer to the ops that read it
+    int phase = 0, site_no = 0;
+    std::map<const void*, float> buf_scale;
+    struct Site { float scale; unsigned* stat; };
+    Site site(const void* buf, const void* alias = nullptr) {
+        const int id = site_no++;
+        if (dry() || rc != A3R_OK) return {1.f, nullptr};
+        if (id >= a3r_model_s::MAX_SITES) {
+            set_error("a3r_model_forward: more than %d fh2 sites in the launch plan", a3r_model_s::MAX_SITES);
+            rc = A3R_ESTATE;
+            return {1.f, nullptr};
+        }
+        std::vector<float>& sc = m->site_scale[phase];
+        if ((int)sc.size() <= id) sc.resize(id + 1, 1.f);
+        buf_scale[buf] = sc[id];
+        if (alias) buf_scale[alias] = sc[id];
+        return {sc[id], m->stats + id};
+    }
+    float scale_of(const void* buf) {
+        if (dry() || rc != A3R_OK) return 1.f;
+        auto it = buf_scale.find(buf);
+        if (it == buf_scale.end()) {
+            set_error("a3r_model_forward: internal: an fh2 operand without a recorded scale");
+            rc = A3R_ESTATE;
+            return 1.f;
+        }
+        return it->second;
+    }
     bool skip() {
         if (ar.overflow && !rc) {
             set_error("a3r_model_forward: internal workspace plan overflow (sizing pass and launch pass disagree)");
@@ -457,8 +501,10 @@ struct Plan {
         if (!bf3()) return x;
         if (skip()) return scratch;
         traced("split_bf3", (int)M, K);
-        if (fh2()) rc = a3r_split_fh2(x, K, scratch, M, K, 1.f, stream);
-        else rc = pair ? a3r_split_bf3_w(x, K, scratch, M, K, stream) : a3r_split_bf3(x, K, scratch, M, K, stream);
+        if (fh2()) {
+            const Site s = site(scratch);
+            rc = a3r_split_fh2(x, K, scratch, M, K, s.scale, s.stat, stream);
+        } else rc = pair ? a3r_split_bf3_w(x, K, scratch, M, K, stream) : a3r_split_bf3(x, K, scratch, M, K, stream);
         return scratch;
     }
     const std::pair<const void*, float>* twin2(const float* w) {
@@ -479,6 +525,14 @@ struct Plan {
         }
         return it->second;
     }
+    // the range fields of an fh2 launch: the operand's scale, and a site for the fh2 output (y itself or the aux twin)
+    void range_epi(a3r_epilogue& e, const void* x2, const void* y) {
+        e.x_scale = scale_of(x2);
+        if (e.out_fh2 || e.aux_fh2) {
+            const Site s = site(e.out_fh2 ? y : e.aux_fh2);
+            e.out_scale = s.scale; e.out_absmax = s.stat;
+        }
+    }
     // nn.Linear on a GEMM-input buffer (bf3 MFMA path unless A3R_GEMM=f32); plain_x: xg is a plain-rows bf3 matrix (DPT maps)
     void linear(const float* xg, int lda, const float* w, float* y, int ldc, int M, int N, int K, const a3r_epilogue& e0,
                 bool plain_x = false) {
@@ -486,8 +540,9 @@ struct Plan {
         traced("linear", M, N, K);
         if (fh2() && (!plain_x || cf2())) {
             const auto* w2 = twin2(w);
-            const a3r_epilogue e = plain_x ? map_epi(e0) : e0;
-            if (w2) rc = a3r_linear_fh2(xg, w2->first, w2->second, y, ldc, M, N, K, &e, stream);
+            a3r_epilogue e = plain_x ? map_epi(e0) : e0;
+            range_epi(e, xg, y);
+            if (w2 && !rc) rc = a3r_linear_fh2(xg, w2->first, w2->second, y, ldc, M, N, K, &e, stream);
         } else if (bf3()) {
             const void* w3 = twin(w);
             a3r_epilogue e = e0;
@@ -513,8 +568,12 @@ struct Plan {
         if (fh2()) {
             const auto *w20 = twin2(w0), *w21 = twin2(w1);
             if (!w20 || !w21) return;
-            a3r_group_ptrs_fh2 g[2] = {{x0, w20->first, y0, b0, r0, nullptr, w20->second}, {x1, w21->first, y1, b1, r1, nullptr, w21->second}};
-            rc = a3r_linear_fh2_grouped(g, 2, ldc, M, N, K, &e, stream);
+            // the two sides' outputs are ONE site (one scale: the attention kernel reads both sides in one launch)
+            Site so = {1.f, nullptr};
+            if (e.out_fh2) so = site(y0, y1);
+            a3r_group_ptrs_fh2 g[2] = {{x0, w20->first, y0, b0, r0, nullptr, w20->second, scale_of(x0), so.scale, so.stat},
+                                       {x1, w21->first, y1, b1, r1, nullptr, w21->second, scale_of(x1), so.scale, so.stat}};
+            if (!rc) rc = a3r_linear_fh2_grouped(g, 2, ldc, M, N, K, &e, stream);
         } else if (bf3()) {
             const void *w30 = twin(w0), *w31 = twin(w1);
             if (!w30 || !w31) return;
@@ -531,15 +590,19 @@ struct Plan {
     void split(const float* x, float* y3, long M, int K) {
         if (skip()) return;
         traced("split_map", (int)M, K);
-        rc = cf2() ? a3r_split_fh2(x, K, y3, M, K, 1.f, stream) : a3r_split_bf3(x, K, y3, M, K, stream);
+        if (cf2()) {
+            const Site s = site(y3);
+            rc = a3r_split_fh2(x, K, y3, M, K, s.scale, s.stat, stream);
+        } else rc = a3r_split_bf3(x, K, y3, M, K, stream);
     }
     void conv3(const float* x3, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e0) {
         if (skip()) return;
         traced("conv3x3_map", H, W, Cin);
         if (cf2()) {
             const auto* w2 = twin2(wp);
-            const a3r_epilogue e = map_epi(e0);
-            if (w2) rc = a3r_conv3x3_fh2(x3, w2->first, w2->second, y, B, H, W, Cin, Cout, stride, &e, stream);
+            a3r_epilogue e = map_epi(e0);
+            range_epi(e, x3, y);
+            if (w2 && !rc) rc = a3r_conv3x3_fh2(x3, w2->first, w2->second, y, B, H, W, Cin, Cout, stride, &e, stream);
             return;
         }
         const void* w3 = twin(wp);
@@ -548,14 +611,19 @@ struct Plan {
     void up3(const float* x, float* y3, int B, int H, int W, int C, int Hc, int Wc) {
         if (skip()) return;
         traced("upsample2x_map", H, W, C);
-        rc = cf2() ? a3r_upsample2x_fh2(x, y3, B, H, W, C, Hc, Wc, stream) : a3r_upsample2x_bf3(x, y3, B, H, W, C, Hc, Wc, stream);
+        if (cf2()) {
+            const Site s = site(y3);
+            rc = a3r_upsample2x_fh2(x, y3, B, H, W, C, Hc, Wc, s.scale, s.stat, stream);
+        } else rc = a3r_upsample2x_bf3(x, y3, B, H, W, C, Hc, Wc, stream);
     }
     // LayerNorm whose output feeds a GEMM (written directly in bf3 form in bf3 mode)
     void ln(const float* x, const float* w, const float* b, float* yg, int M, int D) {
         if (skip()) return;
         traced("layernorm", M, D);
-        rc = fh2() ? a3r_layernorm_fh2(x, w, b, yg, M, D, 1e-6f, stream)
-                   : bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, pair, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
+        if (fh2()) {
+            const Site s = site(yg);
+            rc = a3r_layernorm_fh2(x, w, b, yg, M, D, 1e-6f, s.scale, s.stat, stream);
+        } else rc = bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, pair, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
     }
     void ln_f32(const float* x, const float* w, const float* b, float* y, int M, int D) {
         if (skip()) return;
@@ -563,12 +631,21 @@ struct Plan {
         rc = a3r_layernorm(x, w, b, y, M, D, 1e-6f, stream);
     }
     // q, k, v, o are gin buffers (bf3 mode: straight from / to the projection GEMMs, no fp32 round trip)
-    void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk) {
+    // kv_buf: the buffer k and v are columns of when it is not q's (cross-attention); o_alias: the second side's rows of o when the
+    // consumer addresses them by their own pointer (linear2)
+    void attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B, int H, int Nq, int Nk,
+              const float* kv_buf = nullptr, const float* o_alias = nullptr) {
         if (skip()) return;
         traced("attention", B, Nq, Nk);
-        rc = fh2() ? a3r_attention_fh2(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream)
-                   : bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, pair, stream)
-                           : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
+        if (fh2()) {
+            const float sq = scale_of(q), skv = kv_buf ? scale_of(kv_buf) : sq;
+            const Site so = site(o, o_alias);
+            const a3r_fh2_attn_range r = {sq, skv, skv, so.scale, so.stat};
+            if (!rc) rc = a3r_attention_fh2(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, &r, stream);
+            return;
+        }
+        rc = bf3() ? a3r_attention_bf3(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, pair, stream)
+                   : a3r_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, H, Nq, Nk, stream);
     }
     void conv(const float* x, const float* wp, float* y, int B, int H, int W, int Cin, int Cout, int stride, const a3r_epilogue& e) {
         if (skip()) return;
@@ -725,7 +802,19 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         ~ProductsGuard() { if (on) a3r_bf3_set_products(prev); }
     } products_guard(!dry && m->use_bf3, m->products);
     Plan P;
-    P.m = m; P.stream = stream;
+    P.m = m; P.stream = stream; P.phase = phase;
+    if (!dry && m->use_bf3 && m->use_fh2) {
+        if (hipMemsetAsync(m->stats, 0, (size_t)a3r_model_s::MAX_SITES * 4, as_stream(stream)) != hipSuccess) {
+            set_error("a3r_model_forward: clearing the range statistics failed");
+            return A3R_EHIP;
+        }
+        m->last_phase = phase;
+        m->last_sites = 0;
+    }
+    struct SitesGuard {      // however the plan returns: how many sites it walked
+        a3r_model_s* m; Plan* P; bool on;
+        ~SitesGuard() { if (on) m->last_sites = P->site_no < a3r_model_s::MAX_SITES ? P->site_no : a3r_model_s::MAX_SITES; }
+    } sites_guard{m, &P, !dry};
     static const bool plain_act = getenv("A3R_BF3_PLAIN_ACT") != nullptr;      // A/B switch: keep every activation in plain rows
     P.pair = m->use_bf3 && !m->use_fh2 && BN % 2 == 0 && !plain_act;
     P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};
@@ -847,7 +936,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 float* att1 = P.gin_at(att, BN, D);
                 P.linear2(xn, xn1, D, w0.qkvw, w1.qkvw, w0.qkvb, w1.qkvb, qkv, P.att_at(qkv, BN, 3 * D), 3 * D, BN, 3 * D, D,
                           P.rope_epi(nullptr, 2 * D, N, nw));
-                P.attn(qkv, 3 * D, P.gin_col(qkv, D), 3 * D, P.gin_col(qkv, 2 * D), 3 * D, att, D, 2 * B, c.dec_num_heads, N, N);
+                P.attn(qkv, 3 * D, P.gin_col(qkv, D), 3 * D, P.gin_col(qkv, 2 * D), 3 * D, att, D, 2 * B, c.dec_num_heads, N, N, nullptr, att1);
                 P.linear2(att, att1, D, w0.projw, w1.projw, w0.projb, w1.projb, o0, o1, D, BN, D, D,
                           P.epi(A3R_EPI_RESID, nullptr), x0, x1);
                 // y_ = norm_y(y); x = x + cross_attn(norm2(x), y_, y_)     blocks.py:188-189
@@ -858,7 +947,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
                 P.linear2(xn, xn1, D, w0.qw, w1.qw, w0.qb, w1.qb, qb, P.att_at(qb, BN, D), D, BN, D, D, P.rope_epi(nullptr, D, N, nw));
                 P.linear2(yn, yn1, D, w0.kvw, w1.kvw, w0.kvb, w1.kvb, kv, P.att_at(kv, BN, 2 * D), 2 * D, BN, 2 * D, D,
                           P.rope_epi(nullptr, D, N, nw));
-                P.attn(qb, D, kv, 2 * D, P.gin_col(kv, D), 2 * D, att, D, 2 * B, c.dec_num_heads, N, N);
+                P.attn(qb, D, kv, 2 * D, P.gin_col(kv, D), 2 * D, att, D, 2 * B, c.dec_num_heads, N, N, kv, att1);
                 P.linear2(att, att1, D, w0.cprojw, w1.cprojw, w0.cprojb, w1.cprojb, o0, o1, D, BN, D, D,
                           P.epi(A3R_EPI_RESID, nullptr), o0, o1);
                 // x = x + mlp(norm3(x))                                    blocks.py:190
@@ -1081,5 +1170,48 @@ extern "C" int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr,
     A3R_CHECK_ARG(it != m->taps.end(), "a3r_model_tap: unknown tap '%s' (run a forward first)", name);
     *ptr = it->second.first;
     *count = it->second.second;
+    return A3R_OK;
+}
+
+// ------------------------------------------------------------------------------------------- fh2 range control
+extern "C" int a3r_model_range_check(a3r_model_t m, void* stream, int* n_adjusted, int* n_nonfinite) {
+    A3R_CHECK_ARG(m && n_adjusted && n_nonfinite, "a3r_model_range_check: null argument");
+    *n_adjusted = 0;
+    *n_nonfinite = 0;
+    if (!(m->use_bf3 && m->use_fh2) || m->last_phase < 0 || m->last_sites <= 0) return A3R_OK;     // fp32-range modes / nothing ran
+    std::vector<unsigned> st((size_t)m->last_sites);
+    A3R_HIP(hipMemcpyAsync(st.data(), m->stats, st.size() * 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    A3R_HIP(hipStreamSynchronize(as_stream(stream)));
+    std::vector<float>& sc = m->site_scale[m->last_phase];
+    if (sc.size() < st.size()) sc.resize(st.size(), 1.f);
+    for (size_t i = 0; i < st.size(); i++) {
+        float stored;                                        // max |scale * x| the site wrote
+        static_assert(sizeof(float) == sizeof(unsigned), "bit pattern");
+        memcpy(&stored, &st[i], 4);
+        if (st[i] == 0) continue;                            // an all-zero tensor (or a site that did not run) says nothing
+        if (!std::isfinite(stored)) { (*n_nonfinite)++; continue; }
+        if (stored >= 0.25f && stored <= 32768.f) continue;  // [2^-2, 2^15]: fp32-grade (fh2.h)
+        // new scale: the power of two that puts max |x| = stored / scale into [2^11, 2^12)
+        int e;
+        std::frexp(stored / sc[i], &e);                      // = f 2^e, f in [0.5, 1)   (the division by a power of two is exact)
+        int k = 12 - e;
+        k = k < -40 ? -40 : k > 40 ? 40 : k;              // (products of two scales stay far inside fp32)
+        sc[i] = std::ldexp(1.f, k);
+        (*n_adjusted)++;
+    }
+    return A3R_OK;
+}
+
+extern "C" int a3r_model_range_scales(a3r_model_t m, int phase, float* scales, int capacity, int* n_sites) {
+    A3R_CHECK_ARG(m && n_sites && phase >= 0 && phase < 3 && (scales || capacity == 0), "a3r_model_range_scales: bad argument");
+    const std::vector<float>& sc = m->site_scale[phase];
+    *n_sites = (int)sc.size();
+    for (int i = 0; i < capacity && i < (int)sc.size(); i++) scales[i] = sc[i];
+    return A3R_OK;
+}
+
+extern "C" int a3r_model_reset_ranges(a3r_model_t m) {
+    A3R_CHECK_ARG(m, "a3r_model_reset_ranges: null handle");
+    for (auto& v : m->site_scale) v.clear();
     return A3R_OK;
 }

@@ -7,6 +7,7 @@ a3r_model_forward.  Mirrors what AsymmetricCroCo3DStereo.forward returns (dust3r
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict
 
 import numpy as np
@@ -42,6 +43,8 @@ class PairEngine:
                 self.weights[name] = t
                 shp = (C.c_int64 * t.dim())(*t.shape)
                 check(self.lib.a3r_model_set_weight(self.handle, name.encode(), ptr(t), t.dim(), shp), name)
+            self.range_check = os.environ.get("A3R_RANGE_CHECK", "1") != "0"
+            self.range_reruns = 0          # forwards repeated because an fh2 site left its range (diagnostic)
             nbytes = self.lib.a3r_model_packed_bytes(self.handle)
             self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             check(self.lib.a3r_model_finalize(self.handle, ptr(self.packed), nbytes, stream_ptr()), "a3r_model_finalize")
@@ -55,6 +58,25 @@ class PairEngine:
                 self.handle = None
         except Exception:
             pass
+
+    def _ranged(self, launch, what):
+        """Run `launch` (one a3r_model_forward / _encode / _decode call) under the range control of the default fh2 arithmetic
+        (include/a3r.h, a3r_model_range_check): a site whose activations left the fp16-safe band gets a new power-of-two scale and
+        the call is repeated -- a checkpoint with large (or tiny) activations costs a repeated forward once, never a wrong result.
+        One 4-byte-per-site read-back per call; A3R_RANGE_CHECK=0 skips it (then the caller owns the check)."""
+        for attempt in range(9):
+            launch()
+            if not self.range_check:
+                return
+            n_adj, n_bad = C.c_int(), C.c_int()
+            check(self.lib.a3r_model_range_check(self.handle, stream_ptr(), C.byref(n_adj), C.byref(n_bad)), "a3r_model_range_check")
+            if n_adj.value == 0 and n_bad.value == 0:
+                return
+            self.range_reruns += 1
+            if n_adj.value == 0:      # non-finite statistics with nothing left to rescale: the inputs or weights are not finite
+                break
+        raise RuntimeError(f"{what}: activations are not finite (non-finite inputs or weights?) -- the fh2 range control could not "
+                           "bring every site into range; A3R_GEMM=bf3 runs the same forward with fp32 range")
 
     def workspace_bytes(self, B, H, W):
         return int(self.lib.a3r_model_workspace_bytes(self.handle, B, H, W))
@@ -76,9 +98,10 @@ class PairEngine:
             if out is None:
                 out = dict(pts3d_1=torch.empty((B, H, W, 3), device=self.device), conf_1=torch.empty((B, H, W), device=self.device),
                            pts3d_2=torch.empty((B, H, W, 3), device=self.device), conf_2=torch.empty((B, H, W), device=self.device))
-            check(self.lib.a3r_model_forward(self.handle, ptr(img1), ptr(img2), ptr(pd1), ptr(pd2), B, H, W,
-                                             ptr(out["pts3d_1"]), ptr(out["conf_1"]), ptr(out["pts3d_2"]), ptr(out["conf_2"]),
-                                             ptr(self.workspace), self.workspace.numel(), stream_ptr()), "a3r_model_forward")
+            self._ranged(lambda: check(self.lib.a3r_model_forward(
+                self.handle, ptr(img1), ptr(img2), ptr(pd1), ptr(pd2), B, H, W, ptr(out["pts3d_1"]), ptr(out["conf_1"]),
+                ptr(out["pts3d_2"]), ptr(out["conf_2"]), ptr(self.workspace), self.workspace.numel(), stream_ptr()), "a3r_model_forward"),
+                "a3r_model_forward")
         return out
 
     def _workspace(self, need):
@@ -96,8 +119,9 @@ class PairEngine:
                 raise RuntimeError(f"Input image size ({H}x{W}) is not a multiple of patch size (16).")
             ws = self._workspace(need)
             feat = torch.empty((B, (H // 16) * (W // 16), self.cfg.enc_embed_dim), device=self.device)
-            check(self.lib.a3r_model_encode(self.handle, ptr(img.contiguous()), B, H, W, ptr(feat), ptr(ws), ws.numel(), stream_ptr()),
-                  "a3r_model_encode")
+            img = img.contiguous()
+            self._ranged(lambda: check(self.lib.a3r_model_encode(self.handle, ptr(img), B, H, W, ptr(feat), ptr(ws), ws.numel(), stream_ptr()),
+                                       "a3r_model_encode"), "a3r_model_encode")
         return feat
 
     def decode(self, feat1, feat2, pd1, pd2, H, W, out=None):
@@ -108,10 +132,21 @@ class PairEngine:
             if out is None:
                 out = dict(pts3d_1=torch.empty((B, H, W, 3), device=self.device), conf_1=torch.empty((B, H, W), device=self.device),
                            pts3d_2=torch.empty((B, H, W, 3), device=self.device), conf_2=torch.empty((B, H, W), device=self.device))
-            check(self.lib.a3r_model_decode(self.handle, ptr(feat1.contiguous()), ptr(feat2.contiguous()), ptr(pd1.contiguous()),
-                                            ptr(pd2.contiguous()), B, H, W, ptr(out["pts3d_1"]), ptr(out["conf_1"]), ptr(out["pts3d_2"]),
-                                            ptr(out["conf_2"]), ptr(ws), ws.numel(), stream_ptr()), "a3r_model_decode")
+            f1, f2, d1, d2 = feat1.contiguous(), feat2.contiguous(), pd1.contiguous(), pd2.contiguous()
+            self._ranged(lambda: check(self.lib.a3r_model_decode(
+                self.handle, ptr(f1), ptr(f2), ptr(d1), ptr(d2), B, H, W, ptr(out["pts3d_1"]), ptr(out["conf_1"]), ptr(out["pts3d_2"]),
+                ptr(out["conf_2"]), ptr(ws), ws.numel(), stream_ptr()), "a3r_model_decode"), "a3r_model_decode")
         return out
+
+    def site_scales(self, phase=0):
+        """(diagnostic) the power-of-two scales of the fh2 sites of plan `phase` (0 forward, 1 encode, 2 decode), in plan order."""
+        n = C.c_int()
+        buf = (C.c_float * 1024)()
+        check(self.lib.a3r_model_range_scales(self.handle, phase, buf, 1024, C.byref(n)), "a3r_model_range_scales")
+        return np.array(buf[:min(n.value, 1024)], dtype=np.float32)
+
+    def reset_ranges(self):
+        check(self.lib.a3r_model_reset_ranges(self.handle), "a3r_model_reset_ranges")
 
     def tap(self, name, cols):
         """Intermediate tensor of the last forward as a [rows, cols] view of the workspace (parity tests)."""

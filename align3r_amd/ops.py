@@ -66,8 +66,11 @@ def layernorm(x, w, b, eps=1e-6, out=None):
 
 
 def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
-                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False, aux_fh2=None):
+                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False, aux_fh2=None, x_scale=0.0, out_scale=0.0, out_absmax=None):
     e = Epilogue()
+    # range control of the fh2 kernels (include/a3r.h): zeros / None = scale 1, no statistics
+    e.x_scale, e.out_scale = float(x_scale), float(out_scale)
+    e.out_absmax = None if out_absmax is None else out_absmax.data_ptr()
     e.out_fh2 = int(out_fh2)
     e.aux_fh2 = None if aux_fh2 is None else aux_fh2.data_ptr()
     e.out_bf3 = int(out_bf3)
@@ -271,13 +274,22 @@ def fh2_weight_scale(w) -> float:
     return float(lib.a3r_fh2_weight_scale(float(out.item())))
 
 
-def split_fh2(x, scale=1.0) -> Fh2:
-    """fp32 x [..., K] -> fh2 of scale * x (a3r_split_fh2)."""
+def absmax_word(device):
+    """A zeroed device word for the range statistics of an fh2 producer (max |stored value| as a float bit pattern)."""
+    return torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def absmax_value(word) -> float:
+    return float(word.view(torch.float32).item())
+
+
+def split_fh2(x, scale=1.0, absmax=None) -> Fh2:
+    """fp32 x [..., K] -> fh2 of scale * x (a3r_split_fh2); absmax: an absmax_word() receiving max |scale * x|."""
     _req(x, "x")
     K = x.shape[-1]
     M = x.numel() // K
     y = torch.empty(M * K * 4, device=x.device, dtype=torch.uint8)
-    check(_lib.load().a3r_split_fh2(ptr(x), K, ptr(y), M, K, float(scale), stream_ptr()), "split_fh2")
+    check(_lib.load().a3r_split_fh2(ptr(x), K, ptr(y), M, K, float(scale), ptr(absmax), stream_ptr()), "split_fh2")
     return Fh2(y, M, K, scale)
 
 
@@ -286,27 +298,26 @@ def split_fh2_w(w) -> Fh2:
     return split_fh2(w, fh2_weight_scale(w))
 
 
-def layernorm_fh2(x, w, b, eps=1e-6) -> Fh2:
+def layernorm_fh2(x, w, b, eps=1e-6, scale=1.0, absmax=None) -> Fh2:
     _req(x, "x")
     D = x.shape[-1]
     M = x.numel() // D
     y = torch.empty(M * D * 4, device=x.device, dtype=torch.uint8)
-    check(_lib.load().a3r_layernorm_fh2(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(y), M, D, eps, stream_ptr()), "layernorm_fh2")
-    return Fh2(y, M, D)
+    check(_lib.load().a3r_layernorm_fh2(ptr(x), ptr(_req(w, "w")), ptr(_req(b, "b")), ptr(y), M, D, eps, float(scale), ptr(absmax),
+                                        stream_ptr()), "layernorm_fh2")
+    return Fh2(y, M, D, scale)
 
 
 def linear_fh2(x2: Fh2, w2: Fh2, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
-    """nn.Linear on the fp16 matrix cores with fp32-GEMM accuracy: x2 [M, K] (scale 1), w2 [N, K] in fh2 form (a3r_linear_fh2).
-    out_fh2=True returns an Fh2, out_bf3=True a Bf3 (the attention kernel's operand format), otherwise fp32 [M, N]."""
+    """nn.Linear on the fp16 matrix cores with fp32-GEMM accuracy: x2 [M, K], w2 [N, K] in fh2 form with their own power-of-two
+    scales (a3r_linear_fh2).  out_fh2=True returns an Fh2 (stored with out_scale), out_bf3=True a Bf3, otherwise fp32 [M, N]."""
     M, K, N = x2.rows, x2.K, w2.rows
     if w2.K != K:
         raise RuntimeError(f"linear_fh2: K mismatch ({K} vs {w2.K})")
-    if x2.scale != 1.0:
-        raise RuntimeError("linear_fh2: the activation operand must have scale 1")
-    e = make_epilogue(epi, bias, **kw)
+    e = make_epilogue(epi, bias, x_scale=x2.scale, **kw)
     dev = x2.data.device
     if e.out_fh2:
-        y = Fh2(torch.zeros(M * N * 4, device=dev, dtype=torch.uint8), M, N)
+        y = Fh2(torch.zeros(M * N * 4, device=dev, dtype=torch.uint8), M, N, e.out_scale or 1.0)
         check(_lib.load().a3r_linear_fh2(x2.data_ptr(), w2.data_ptr(), w2.scale, y.data_ptr(), N, M, N, K, C.byref(e), stream_ptr()), "linear_fh2")
         return y
     if e.out_bf3:
@@ -319,7 +330,7 @@ def linear_fh2(x2: Fh2, w2: Fh2, bias=None, epi=_lib.EPI_NONE, out=None, **kw):
     return out
 
 
-def linear_fh2_grouped(x2s, w2s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
+def linear_fh2_grouped(x2s, w2s, biases, epi=_lib.EPI_NONE, resids=None, out_scale=0.0, out_absmax=None, **kw):
     G = len(x2s)
     M, K, N = x2s[0].rows, x2s[0].K, w2s[0].rows
     outs = [torch.empty((M, N), device=x2s[0].data.device, dtype=torch.float32) for _ in range(G)]
@@ -329,17 +340,21 @@ def linear_fh2_grouped(x2s, w2s, biases, epi=_lib.EPI_NONE, resids=None, **kw):
         arr[i].bias = None if biases is None else biases[i].data_ptr()
         arr[i].resid = None if resids is None else resids[i].data_ptr()
         arr[i].w_scale = w2s[i].scale
+        arr[i].x_scale = x2s[i].scale
+        arr[i].out_scale = float(out_scale)
+        arr[i].out_absmax = None if out_absmax is None else out_absmax.data_ptr()
     e = make_epilogue(epi, **kw)
     check(_lib.load().a3r_linear_fh2_grouped(arr, G, N, M, N, K, C.byref(e), stream_ptr()), "linear_fh2_grouped")
     return outs
 
 
-def attention_fh2(q2: Fh2, k2: Fh2, v2: Fh2, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0) -> Fh2:
+def attention_fh2(q2: Fh2, k2: Fh2, v2: Fh2, B, H, Nq, Nk, q_col=0, k_col=0, v_col=0, out_scale=1.0, out_absmax=None) -> Fh2:
     """softmax(q k^T / 8) v per head (head_dim 64) on fh2 operands (a3r_attention_fh2); q2/k2/v2 may be column slices (start column,
-    multiple of 8) of wider fh2 matrices.  Returns the fh2 [B*Nq, H*64] output."""
-    o2 = Fh2(torch.zeros(B * Nq * H * 64 * 4, device=q2.data.device, dtype=torch.uint8), B * Nq, H * 64)
+    multiple of 8) of wider fh2 matrices, each stored with its own scale.  Returns the fh2 [B*Nq, H*64] output (stored with out_scale)."""
+    o2 = Fh2(torch.zeros(B * Nq * H * 64 * 4, device=q2.data.device, dtype=torch.uint8), B * Nq, H * 64, out_scale)
+    r = _lib.Fh2AttnRange(q2.scale, k2.scale, v2.scale, float(out_scale), None if out_absmax is None else out_absmax.data_ptr())
     check(_lib.load().a3r_attention_fh2(q2.data_ptr() + q_col * 4, q2.K, k2.data_ptr() + k_col * 4, k2.K, v2.data_ptr() + v_col * 4, v2.K,
-                                        o2.data_ptr(), H * 64, B, H, Nq, Nk, stream_ptr()), "attention_fh2")
+                                        o2.data_ptr(), H * 64, B, H, Nq, Nk, C.byref(r), stream_ptr()), "attention_fh2")
     return o2
 
 
@@ -420,10 +435,10 @@ def conv3x3_fh2(x2: Fh2, wp2: Fh2, shape, bias=None, stride=1, epi=_lib.EPI_NONE
     B, H, W, Cin = shape
     Cout = wp2.rows
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    e = make_epilogue(epi, bias, **kw)
+    e = make_epilogue(epi, bias, x_scale=x2.scale, **kw)
     dev = x2.data.device
     if e.out_fh2:
-        out = Fh2(torch.zeros(B * Ho * Wo * Cout * 4, device=dev, dtype=torch.uint8), B * Ho * Wo, Cout)
+        out = Fh2(torch.zeros(B * Ho * Wo * Cout * 4, device=dev, dtype=torch.uint8), B * Ho * Wo, Cout, e.out_scale or 1.0)
     else:
         out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float32)
     check(_lib.load().a3r_conv3x3_fh2(x2.data_ptr(), wp2.data_ptr(), wp2.scale, out.data_ptr(), B, H, W, Cin, Cout, stride, C.byref(e),
@@ -431,13 +446,13 @@ def conv3x3_fh2(x2: Fh2, wp2: Fh2, shape, bias=None, stride=1, epi=_lib.EPI_NONE
     return out
 
 
-def upsample2x_fh2(x, crop=None) -> Fh2:
-    """upsample2x written in fh2 form (rows = output pixels, K = C)."""
+def upsample2x_fh2(x, crop=None, scale=1.0, absmax=None) -> Fh2:
+    """upsample2x written in fh2 form (rows = output pixels, K = C), stored with `scale`."""
     _req(x, "x")
     B, H, W, Cc = x.shape
     Hc, Wc = crop if crop else (2 * H, 2 * W)
-    out = Fh2(torch.zeros(B * Hc * Wc * Cc * 4, device=x.device, dtype=torch.uint8), B * Hc * Wc, Cc)
-    check(_lib.load().a3r_upsample2x_fh2(ptr(x), out.data_ptr(), B, H, W, Cc, Hc, Wc, stream_ptr()), "upsample2x_fh2")
+    out = Fh2(torch.zeros(B * Hc * Wc * Cc * 4, device=x.device, dtype=torch.uint8), B * Hc * Wc, Cc, scale)
+    check(_lib.load().a3r_upsample2x_fh2(ptr(x), out.data_ptr(), B, H, W, Cc, Hc, Wc, float(scale), ptr(absmax), stream_ptr()), "upsample2x_fh2")
     return out
 
 

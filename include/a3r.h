@@ -116,6 +116,13 @@ typedef struct {
     /* fh2 kernels only: ALSO write the result (after bias / activation / residuals; through a ReLU if aux_relu) in fh2 form
      * [M][N/8][2][8] to aux_fh2 -- as aux_bf3, for the DPT convolutions on the fh2 kernel (y, resid, resid2 16-byte aligned). */
     void* aux_fh2;
+    /* fh2 kernels only -- range control of the fh2 operands (see a3r_model_range_check).  All three may stay zero.
+     * x_scale: the power of two the x2 operand was stored with (0 = 1); out_scale: the power of two to store the out_fh2 / aux_fh2
+     * output with (0 = 1: the planes hold out_scale * value); out_absmax: device word that receives max |out_scale * value| over
+     * that output by an atomic max on the bit pattern (NULL: no statistics; the caller zeroes it beforehand).  The grouped entry
+     * point takes them per group (a3r_group_ptrs_fh2) and ignores these. */
+    float x_scale, out_scale;
+    unsigned* out_absmax;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
@@ -184,21 +191,25 @@ int a3r_linear_bf3_grouped(const a3r_group_ptrs_bf3* groups, int n_groups, int l
  * Same call sites as a3r_linear (blocks.py:58-169); epilogues as above (no PIXSHUF), out_bf3 for the projections that feed the
  * attention kernel, out_fh2 (NONE / GELU / RELU / ROPE) for fc1 + GELU -> fc2 and for the q / k / v of a3r_attention_fh2. */
 size_t a3r_fh2_bytes(long rows, int K);
-/* fp32 x [M, ldx] (first K columns) * scale -> fh2 y (K % 8 == 0) */
-int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, void* stream);
+/* fp32 x [M, ldx] (first K columns) * scale -> fh2 y (K % 8 == 0); absmax (device, may be NULL): atomic max of |scale * x| */
+int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, float scale, unsigned* absmax, void* stream);
 /* max |x| over n floats -> *out_dev (device float; the call zeroes it first) and the weight scale derived from it (host helper) */
 int a3r_absmax(const float* x, long n, float* out_dev, void* stream);
 float a3r_fh2_weight_scale(float absmax);
-/* nn.LayerNorm (as a3r_layernorm) writing its output in fh2 form (scale 1; D % 32 == 0) */
-int a3r_layernorm_fh2(const float* x, const float* w, const float* b, void* y2, int M, int D, float eps, void* stream);
+/* nn.LayerNorm (as a3r_layernorm) writing scale * y in fh2 form (D % 32 == 0; scale a power of two, absmax as a3r_split_fh2) */
+int a3r_layernorm_fh2(const float* x, const float* w, const float* b, void* y2, int M, int D, float eps, float scale,
+                      unsigned* absmax, void* stream);
 typedef struct {
-    const void* x2;       /* fh2 [M, K], scale 1 */
+    const void* x2;       /* fh2 [M, K], stored with x_scale */
     const void* w2;       /* fh2 [N, K], stored with w_scale */
     float* y;
     const float* bias;
     const float* resid;
     const float* resid2;
     float w_scale;
+    float x_scale;        /* 0 = 1 */
+    float out_scale;      /* out_fh2 / aux_fh2 output: 0 = 1 */
+    unsigned* out_absmax; /* or NULL */
 } a3r_group_ptrs_fh2;
 int a3r_linear_fh2_grouped(const a3r_group_ptrs_fh2* groups, int n_groups, int ldc, int M, int N, int K, const a3r_epilogue* epi,
                            void* stream);
@@ -244,9 +255,15 @@ int a3r_attention_bf3_fh2out(const void* q3, int ldq, const void* k3, int ldk, c
 /* The same attention on the fp16 matrix cores from fh2 operands (q2 / k2 / v2 / o2: fh2 matrices, pointers to the first column's
  * 32-byte group, leading dimensions in fp32 columns, multiples of 8): three exact fp16 MFMA passes per product, fp32 softmax,
  * P split into two fp16 planes of 1024 p in registers.  Consumes the RoPE + out_fh2 output of a3r_linear_fh2 and produces the fh2
- * input of the output projection. */
+ * input of the output projection.  range (or NULL = all ones, no statistics): the powers of two q2 / k2 / v2 were stored with (divided
+ * out exactly: q_scale k_scale in the exp2 argument, v_scale with the softmax normaliser), the one to store o2 with, and the
+ * device word receiving max |out_scale * o| (see a3r_epilogue.out_absmax); zeros mean 1 / none. */
+typedef struct {
+    float q_scale, k_scale, v_scale, out_scale;
+    unsigned* out_absmax;
+} a3r_fh2_attn_range;
 int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ldk, const void* v2, int ldv, void* o2, int ldo,
-                      int B, int H, int Nq, int Nk, void* stream);
+                      int B, int H, int Nq, int Nk, const a3r_fh2_attn_range* range, void* stream);
 
 /* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
  * HOST buffers. */
@@ -285,8 +302,10 @@ int a3r_pnp_solve(const void* desc, int B, int n_max, int iterations, void* work
 int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 /* the same, written in bf3 form ([B Hc Wc][C/8][3][8] bf16, C % 8 == 0): input of the next conv on the bf3 kernel */
 int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W, int C, int Hc, int Wc, void* stream);
-/* the same, written in fh2 form ([B Hc Wc][C/8][2][8] fp16, C % 8 == 0): input of the next conv on the fh2 kernel */
-int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W, int C, int Hc, int Wc, void* stream);
+/* the same, written in fh2 form ([B Hc Wc][C/8][2][8] fp16 planes of scale * y, C % 8 == 0): input of the next conv on the fh2
+ * kernel; scale a power of two, absmax (device, may be NULL) receives max |scale * y| as in a3r_split_fh2 */
+int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W, int C, int Hc, int Wc, float scale, unsigned* absmax,
+                       void* stream);
 
 /* last 1x1 conv (128 -> 4) + postprocess (dpt_block.py:329, postprocess.py:10-58):
  * x [P, C] -> pts3d [P, 3] = xyz/max(|xyz|,1e-8)*expm1(|xyz|), conf [P] = 1 + exp(c). */
@@ -337,6 +356,22 @@ int a3r_model_decode(a3r_model_t m, const float* feat1, const float* feat2, cons
 /* Debug taps for the parity tests: copies of intermediate tensors inside the workspace after a forward.
  * name in {"enc1","dec1_6","dec1_last","dec2_last","pc_tokens","raw1"}; returns device pointer + element count. */
 int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count);
+
+/* Range control of the default (fh2) arithmetic.  The reference computes in fp32 (croco.py:13 even allows TF32) and has no
+ * activation range limit; two fp16 planes do: a tensor is fp32-grade only while its largest |scale * x| lies in [2^-2, 2^15]
+ * (csrc/fh2.h).  Every site of the launch plan that writes an fh2 tensor therefore carries its own power-of-two scale (initially 1)
+ * and records max |scale * x| during a3r_model_forward / _encode / _decode.  a3r_model_range_check waits for `stream`, reads the
+ * statistics of the LAST such call, and gives every site whose maximum left the band (or was not finite) a new scale that puts it at
+ * [2^11, 2^12).  *n_adjusted = number of sites changed; *n_nonfinite = sites whose maximum was Inf / NaN (their own scale cannot be
+ * derived until the upstream overflow is gone).  When either is non-zero the outputs of that call are NOT fp32-grade (an overflow
+ * makes them Inf / NaN) and the call must be repeated -- the scales persist in the handle, so a checkpoint with large activations
+ * pays this once.  With both zero the outputs are final.  Modes other than fh2 (A3R_GEMM=f32|bf3|...) have fp32 range: always 0.
+ * a3r_model_reset_ranges puts every scale back to 1. */
+int a3r_model_range_check(a3r_model_t m, void* stream, int* n_adjusted, int* n_nonfinite);
+int a3r_model_reset_ranges(a3r_model_t m);
+/* (diagnostic) the current scales of plan `phase` (0 = forward, 1 = encode, 2 = decode), in plan order: *n_sites = their number,
+ * the first min(capacity, *n_sites) are copied to scales (host). */
+int a3r_model_range_scales(a3r_model_t m, int phase, float* scales, int capacity, int* n_sites);
 
 /* ------------------------------------------------------------------------------------------------
  * (4) global alignment inner loop: PointCloudOptimizer (cloud_opt/optimizer.py, base_opt.py)
