@@ -114,6 +114,12 @@ SIGNATURES = {
     "a3r_pnp_chunks": (C.c_int, [C.c_int]),
     "a3r_pnp_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "a3r_pnp_solve": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
+    "a3r_conf_prepare": (C.c_int, [c_void, c_void, C.c_int, C.c_long, C.c_int, c_void, c_void, c_void, c_void]),
+    "a3r_im_conf_max": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_long, c_void, c_void]),
+    "a3r_weiszfeld_focal": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
+    "a3r_sim3_apply": (C.c_int, [c_void, c_void, C.c_int, C.c_float, c_void, C.c_long, c_void]),
+    "a3r_depth_init": (C.c_int, [c_void, c_void, C.c_float, C.c_int, C.c_long, c_void, c_void]),
+    "a3r_mask_gt": (C.c_int, [c_void, C.c_float, c_void, C.c_long, c_void]),
     "a3r_upsample2x_fh2": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_void, c_void]),
     "a3r_conv3x3_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_head_final": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_long, C.c_int, c_void]),
@@ -128,8 +134,10 @@ SIGNATURES = {
     "a3r_model_encode": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, c_void]),
     "a3r_model_decode": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, C.c_size_t, c_void]),
     "a3r_model_tap": (C.c_int, [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_size_t)]),
+    "a3r_model_set_tap_level": (C.c_int, [c_void, C.c_int]),
     "a3r_model_range_check": (C.c_int, [c_void, c_void, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "a3r_model_reset_ranges": (C.c_int, [c_void]),
+    "a3r_model_range_stats": (C.c_int, [c_void, c_void, c_void, C.c_int, C.POINTER(C.c_int)]),
     "a3r_model_range_scales": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.POINTER(C.c_int)]),
     "a3r_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "a3r_align_create": (C.c_int, [C.POINTER(AlignDesc), C.POINTER(c_void), c_void]),

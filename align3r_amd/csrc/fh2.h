@@ -78,4 +78,19 @@ __device__ __forceinline__ void fh2_publish_absmax(unsigned* slot, float m) {
     }
 }
 
+// NaN-aware variant for the HBM-bound producers that read MODEL INPUTS (split passes: images, point maps, weights): the maximum of
+// the bit patterns with the sign cleared, where NaN sorts above Inf -- v_max_f32 ignores a NaN operand, and a NaN that enters the
+// network can end as a finite number (fmaxf(NaN, 0) = 0 in a ReLU), so it must be caught where it enters.  Two VALU ops per element.
+__device__ __forceinline__ unsigned fh2_amax_bits4(unsigned m, f32x4 v) {
+    const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+    const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+    return max(max(m, max(a, b)), max(c, d));
+}
+__device__ __forceinline__ void fh2_publish_absmax_bits(unsigned* slot, unsigned b) {
+    if (!slot) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+}
+
 }  // namespace a3r

@@ -379,24 +379,23 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
 __global__ __launch_bounds__(256) void split_fh2_kernel(const float* __restrict__ x, int ldx, char* __restrict__ y, long M, int K8, float scale,
                                                         unsigned* __restrict__ absmax) {
     const long total = M * K8;
-    float amax = 0.f;
+    unsigned amax = 0;                                      // NaN-aware (fh2.h): this pass is where inputs and raw tokens enter
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long row = i / K8;
         const int kg = (int)(i - row * K8);
         const f32x4* src = reinterpret_cast<const f32x4*>(x + row * ldx + kg * 8);
         const f32x4 lo = src[0] * scale, hi = src[1] * scale;
-        amax = fh2_amax4(fh2_amax4(amax, lo), hi);
+        amax = fh2_amax_bits4(fh2_amax_bits4(amax, lo), hi);
         fh2_store8(y + row * ((size_t)K8 * 32), kg * 8, lo, hi);
     }
-    fh2_publish_absmax(absmax, amax);                       // every lane arrives here
+    fh2_publish_absmax_bits(absmax, amax);                  // every lane arrives here
 }
 
 // max |x| of n floats -> *out (a non-negative float compared as an unsigned integer; *out must be zero before the launch)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
-    float m = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    unsigned m = 0;                                         // bit patterns with the sign cleared: a NaN weight sorts above everything
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    fh2_publish_absmax_bits(out, m);
 }
 
 struct Fh2Tile { int bm, bn, occ; double eff; };

@@ -78,6 +78,7 @@ struct a3r_model_s {
     std::vector<float> site_scale[3];
     unsigned* stats = nullptr;       // [MAX_SITES], inside the packed buffer
     int last_phase = -1, last_sites = 0;
+    int tap_level = 0;               // a3r_model_set_tap_level: decoder level copied to the taps "level" / "pc0" (parity tests), 0 = none
 };
 
 static int n_pc_blocks(const a3r_model_config& c) { return c.dec_depth / 2 - 2; }
@@ -398,6 +399,10 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
             float amax = 0.f;
             A3R_HIP(hipMemcpyAsync(&amax, scratch, 4, hipMemcpyDeviceToHost, st));
             A3R_HIP(hipStreamSynchronize(st));
+            if (!std::isfinite(amax)) {
+                set_error("a3r_model_finalize: weight '%s' contains non-finite values", it.name.c_str());
+                return A3R_EINVAL;
+            }
             const float scale = a3r_fh2_weight_scale(amax);
             if (int rc = a3r_split_fh2(src, it.b, dst, it.a, it.b, scale, nullptr, stream)) return rc;
             m->w2[src] = {dst, scale};
@@ -848,6 +853,16 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
     float* fbuf[4];
     for (int i = 0; i < 4; i++) fbuf[i] = ar.alloc((size_t)M2 * D);   // ping, pong, hook A, hook B
     float* dec_last = ar.alloc((size_t)M2 * D);
+    // debug taps (a3r_model_set_tap_level): copies of one decoder level and of the point-cloud tokens before their first block
+    float* tap_lvl = m->tap_level > 0 ? ar.alloc((size_t)M2 * D) : nullptr;
+    float* tap_pc0 = m->tap_level > 0 ? ar.alloc((size_t)M2 * D) : nullptr;
+    auto tap_copy = [&](float* dst, const float* src) {
+        if (dry || P.rc != A3R_OK || !dst) return;
+        if (hipMemcpyAsync(dst, src, (size_t)M2 * D * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) {
+            set_error("a3r_model_forward: tap copy failed");
+            P.rc = A3R_EHIP;
+        }
+    };
     const size_t mark = ar.off;
     // ---------------- encoder (model.py:151-163)
     if (phase == 2) {
@@ -892,6 +907,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         P.linear(P.gin_from(cols, cols3, M2, 768), 768, m->pepc_w, pc, D, M2, D, 768, P.epi(A3R_EPI_NONE, m->pepc_b));
     }
     ar.off = mark;
+    tap_copy(tap_pc0, pc);
     // ---------------- decoder (model.py:201-233)
     const int hook_a = c.dec_depth * 2 / 4, hook_b = c.dec_depth * 3 / 4;   // levels 6 and 9 for depth 12
     const float *lvl_a = nullptr, *lvl_b = nullptr;
@@ -966,6 +982,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             }
             if (level == hook_a) lvl_a = nxt;
             if (level == hook_b) lvl_b = nxt;
+            if (level == m->tap_level) tap_copy(tap_lvl, nxt);
             cur = nxt;
         }
         P.ln_f32(cur, m->decn_w, m->decn_b, dec_last, M2, D);   // model.py:231-232
@@ -977,6 +994,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         m->taps["hook_a"] = {lvl_a, (size_t)M2 * D};
         m->taps["hook_b"] = {lvl_b, (size_t)M2 * D};
         m->taps["dec_last"] = {dec_last, (size_t)M2 * D};
+        if (tap_lvl) { m->taps["level"] = {tap_lvl, (size_t)M2 * D}; m->taps["pc0"] = {tap_pc0, (size_t)M2 * D}; }
     }
     // ---------------- DPT heads (dpt_head.py:34-66), one per view, fp32
     for (int s = 0; s < 2; s++) {
@@ -1164,6 +1182,12 @@ extern "C" int a3r_model_decode(a3r_model_t m, const float* feat1, const float* 
                     nullptr, 2, feat1, feat2, nullptr);
 }
 
+extern "C" int a3r_model_set_tap_level(a3r_model_t m, int level) {
+    A3R_CHECK_ARG(m && level >= 0 && level <= m->cfg.dec_depth, "a3r_model_set_tap_level: level must be in 0..dec_depth");
+    m->tap_level = level;
+    return A3R_OK;
+}
+
 extern "C" int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count) {
     A3R_CHECK_ARG(m && name && ptr && count, "a3r_model_tap: null argument");
     auto it = m->taps.find(name);
@@ -1199,6 +1223,16 @@ extern "C" int a3r_model_range_check(a3r_model_t m, void* stream, int* n_adjuste
         sc[i] = std::ldexp(1.f, k);
         (*n_adjusted)++;
     }
+    return A3R_OK;
+}
+
+extern "C" int a3r_model_range_stats(a3r_model_t m, void* stream, float* stored_absmax, int capacity, int* n_sites) {
+    A3R_CHECK_ARG(m && n_sites && (stored_absmax || capacity == 0), "a3r_model_range_stats: bad argument");
+    *n_sites = m->last_sites;
+    const int n = capacity < m->last_sites ? capacity : m->last_sites;
+    if (n <= 0 || !m->stats) return A3R_OK;
+    A3R_HIP(hipMemcpyAsync(stored_absmax, m->stats, (size_t)n * 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    A3R_HIP(hipStreamSynchronize(as_stream(stream)));
     return A3R_OK;
 }
 

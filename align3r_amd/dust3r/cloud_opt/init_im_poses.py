@@ -353,10 +353,175 @@ def edge_views(scene, dev):
             [cj[e, :sh[j][0] * sh[j][1]].view(*sh[j]) for e, (i, j) in enumerate(scene.edges)])
 
 
+# ------------------------------------------------------------------------------------------------ device fast path
+def _quat_xyzw_np(R):
+    """[B,3,3] rotation matrices (numpy) -> [B,4] XYZW unit quaternions; branch selection as commons.rotmat_to_unitquat."""
+    R = np.asarray(R, dtype=np.float64)
+    m = lambda i, j: R[:, i, j]
+    tr = m(0, 0) + m(1, 1) + m(2, 2)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        s0 = np.sqrt(np.maximum(tr + 1.0, 1e-300)) * 2
+        b0 = np.stack([(m(2, 1) - m(1, 2)) / s0, (m(0, 2) - m(2, 0)) / s0, (m(1, 0) - m(0, 1)) / s0, 0.25 * s0], -1)
+        s1 = np.sqrt(np.maximum(1.0 + m(0, 0) - m(1, 1) - m(2, 2), 1e-300)) * 2
+        b1 = np.stack([0.25 * s1, (m(0, 1) + m(1, 0)) / s1, (m(0, 2) + m(2, 0)) / s1, (m(2, 1) - m(1, 2)) / s1], -1)
+        s2 = np.sqrt(np.maximum(1.0 + m(1, 1) - m(0, 0) - m(2, 2), 1e-300)) * 2
+        b2 = np.stack([(m(0, 1) + m(1, 0)) / s2, 0.25 * s2, (m(1, 2) + m(2, 1)) / s2, (m(0, 2) - m(2, 0)) / s2], -1)
+        s3 = np.sqrt(np.maximum(1.0 + m(2, 2) - m(0, 0) - m(1, 1), 1e-300)) * 2
+        b3 = np.stack([(m(0, 2) + m(2, 0)) / s3, (m(1, 2) + m(2, 1)) / s3, 0.25 * s3, (m(1, 0) - m(0, 1)) / s3], -1)
+    c0 = (tr > 0)[:, None]
+    c1 = ((m(0, 0) > m(1, 1)) & (m(0, 0) > m(2, 2)))[:, None]
+    c2 = (m(1, 1) > m(2, 2))[:, None]
+    return np.where(c0, b0, np.where(c1, b1, np.where(c2, b2, b3))).astype(np.float32)
+
+
+def _signed_log1p_np(x):
+    return (np.sign(x) * np.log1p(np.abs(x))).astype(np.float32)
+
+
+def _mst_device(scene, niter_PnP=10):
+    """init_minimum_spanning_tree + init_from_pts3d for a problem whose images share one shape and whose predictions are on the GPU:
+    the same steps as the generic code below, with every per-pixel pass a launch of liba3r (csrc/init_maps.hip, the Umeyama / PnP
+    solvers of init.hip) and the algebra on poses / quaternions in numpy on the host from three small read-backs -- no torch
+    arithmetic on the device, hence no dependence on which torch kernels (or rocBLAS) a process has loaded so far: the first call
+    costs what every later call costs."""
+    import ctypes as C
+    from ... import _lib
+    from ..._lib import check, ptr, stream_ptr
+    from . import _native
+    lib = _lib.load()
+    eng = scene._need_engine()
+    dev = eng.device
+    edges = [tuple(e) for e in scene.edges]
+    E, N, P = len(edges), scene.n_imgs, scene.max_area
+    H, W = scene.imshape
+    eidx = {e: k for k, e in enumerate(edges)}
+    pred_i, pred_j = eng.pred_i, eng.pred_j                                  # [E, P, 3]
+    conf_i, conf_j = scene._raw_conf_i, scene._raw_conf_j                    # [E, P]
+    # ---- edge scores (commons.py:20-25) and every edge's Weiszfeld focal of its first view: two launches, one read-back each
+    mean = scene._edge_conf_mean
+    if mean is None:
+        _, _, mean = _native.conf_prepare(conf_i, conf_j, 'id', want_weights=False)
+    focal_dev = _native.weiszfeld_focal(pred_i.view(E, H, W, 3))
+    mean = mean.cpu().numpy()
+    edge_focal = focal_dev.cpu().numpy().tolist()
+    scores = {e: float(np.float32(mean[2 * k]) * np.float32(mean[2 * k + 1])) for k, e in enumerate(edges)}
+    graph = sp.dok_array((N, N))
+    for (i, j), v in scores.items():
+        graph[i, j] = -v
+    msp = sp.csgraph.minimum_spanning_tree(graph).tocoo()
+    todo = sorted(zip(-msp.data, msp.row.tolist(), msp.col.tolist()))
+    # ---- the walk over the tree is decided on the host (it depends on the scores only), then enqueued: per tree edge one
+    # registration of the known side onto the world points so far and one similarity applied to the other side
+    im_focals = [None] * N
+    pose_src = {}                                 # image -> 'eye' | index of the tree step whose (R, T) is its pose
+    score, i, j = todo.pop()
+    if scene.verbose:
+        print(f' init edge ({i}*,{j}*) {score=}')
+    k0 = eidx[(i, j)]
+    pts = torch.empty((N, P, 3), dtype=torch.float32, device=dev)
+    pts[i].copy_(pred_i[k0])
+    pts[j].copy_(pred_j[k0])
+    done = {i, j}
+    pose_src[i] = 'eye'
+    im_focals[i] = edge_focal[k0]
+    steps = []                                    # (edge k, known side 0 = i | 1 = j, known image, new image)
+    last_k = k0
+    while todo:
+        score, i, j = todo.pop()
+        if im_focals[i] is None:
+            im_focals[i] = edge_focal[last_k]      # the reference uses the PREVIOUS edge's map here (:199)
+        if i in done:
+            assert j not in done
+            k = last_k = eidx[(i, j)]
+            steps.append((k, 0, i, j))
+            done.add(j)
+        elif j in done:
+            assert i not in done
+            k = last_k = eidx[(i, j)]
+            steps.append((k, 1, j, i))
+            done.add(i)
+        else:
+            todo.insert(0, (score, i, j))
+            continue
+        if i not in pose_src:
+            pose_src[i] = len(steps) - 1
+    T = len(steps)
+    nch = int(lib.a3r_umeyama_chunks(P))
+    st = stream_ptr()
+    if T:
+        off = np.asarray([[k * P * 3, known * P * 3, k * P] for k, _, known, _ in steps], dtype=np.int64)
+        off_dev = torch.from_numpy(np.ascontiguousarray(off.T)).to(dev)          # [3, T]: x, y, w element offsets
+        partial = torch.empty((nch, 17), dtype=torch.float64, device=dev)
+        tree_sols = torch.empty((T, 13), dtype=torch.float32, device=dev)
+        at = lambda t, byte: C.c_void_p(t.data_ptr() + byte)
+        with torch.cuda.device(dev):
+            for t, (k, side, known, new) in enumerate(steps):
+                x, w, other = (pred_i, conf_i, pred_j) if side == 0 else (pred_j, conf_j, pred_i)
+                check(lib.a3r_umeyama_moments(ptr(x), ptr(pts), ptr(w), at(off_dev, 8 * t), at(off_dev, 8 * (T + t)), at(off_dev, 8 * (2 * T + t)),
+                                              1, P, ptr(partial), st), "a3r_umeyama_moments")
+                check(lib.a3r_umeyama_solve(ptr(partial), nch, 1, at(tree_sols, 52 * t), st), "a3r_umeyama_solve")
+                check(lib.a3r_sim3_apply(at(other, 12 * P * k), at(tree_sols, 52 * t), 1, 1.0, at(pts, 12 * P * new), P, st), "a3r_sim3_apply")
+    # ---- all E pairwise registrations pred_i[e] -> pts[i] (init_from_pts3d :100-109), enqueued before the first read-back
+    offs = np.asarray([[e * P * 3 for e in range(E)], [i * P * 3 for i, _ in edges], [e * P for e in range(E)]], dtype=np.int64)
+    offs_dev = torch.from_numpy(offs).to(dev)
+    sols = umeyama_solve(pred_i, pts, conf_i, offs_dev[0], offs_dev[1], offs_dev[2], P)
+    tree = tree_sols.cpu().numpy() if T else np.zeros((0, 13), np.float32)
+    im_poses = np.tile(np.eye(4, dtype=np.float32), (N, 1, 1))
+    for img, src in pose_src.items():
+        if src != 'eye':
+            im_poses[img, :3, :3] = tree[src, 1:10].reshape(3, 3)
+            im_poses[img, :3, 3] = tree[src, 10:13]
+    order = sorted(scores.items(), key=lambda kv: -kv[1])
+    for (i, j), _ in order:
+        if im_focals[i] is None:
+            im_focals[i] = edge_focal[eidx[(i, j)]]
+    missing = [i for i in range(N) if i not in pose_src]                     # every missing pose in ONE device batch
+    if missing:
+        masks = _native.mask_gt(scene._im_conf_stack, scene.min_conf_thr)
+        res = linear_pnp_many([(pts[i].view(H, W, 3), im_focals[i], masks[i].view(H, W), None) for i in missing])
+        for i, r in zip(missing, res):
+            if r:
+                im_focals[i] = r[0]
+                im_poses[i] = r[1].cpu().numpy()
+    sols = sols.cpu().numpy()
+    # ---- pairwise poses, global scale, image poses, depth maps, focals: what init_from_pts3d writes into the optimiser (:100-126)
+    pw = np.empty((E, 8), np.float32)
+    pw[:, 0:4] = _quat_xyzw_np(sols[:, 1:10].reshape(E, 3, 3))
+    pw[:, 4:7] = _signed_log1p_np(sols[:, 10:13] / sols[:, 0:1])
+    pw[:, 7] = np.log(sols[:, 0])
+    s_factor = float(np.exp(np.float32(np.log(scene.base_scale)) - pw[:, 7].mean(dtype=np.float32))) if scene.norm_pw_scale else 1.0
+    im_poses[:, :3, 3] *= np.float32(s_factor)
+    if not scene.if_use_mono:
+        Rt = np.transpose(im_poses[:, :3, :3], (0, 2, 1))
+        w2c = np.concatenate((Rt, -(Rt @ im_poses[:, :3, 3:4])), axis=2).astype(np.float32)          # [N, 3, 4]
+        _native.depth_init(pts, torch.from_numpy(np.ascontiguousarray(w2c)).to(dev), s_factor, eng.params['depth'])
+    new = dict(pw_poses=torch.from_numpy(pw))
+    if eng.flags['train_poses']:
+        poses = np.empty((N, 7), np.float32)
+        poses[:, 0:4] = _quat_xyzw_np(im_poses[:, :3, :3])
+        poses[:, 4:7] = _signed_log1p_np(im_poses[:, :3, 3])
+        new['im_poses'] = torch.from_numpy(poses)
+    if eng.flags['train_focals']:
+        focals = eng.params['im_focals'].cpu().numpy().copy()
+        if getattr(eng, 'shared_focal', False):
+            if im_focals[0] is not None:
+                focals[0] = scene.focal_break * float(np.log(im_focals[0]))
+        else:
+            for i in range(N):
+                if im_focals[i] is not None:
+                    focals[i] = scene.focal_break * float(np.log(im_focals[i]))
+        new['im_focals'] = torch.from_numpy(focals)
+    eng.set_params(**new)
+    if scene.verbose:
+        print(' init loss =', float(scene()))
+
+
 def init_minimum_spanning_tree(scene, init_priors=None, niter_PnP=10):
     """init_minimum_spanning_tree + init_from_pts3d (:69-126) on a mirror PointCloudOptimizer that is already on a device."""
     eng = scene._need_engine()
     dev = eng.device
+    if getattr(scene, '_fast', False) and init_priors is None and eng.flags['train_poses'] and scene.n_imgs > 1:
+        return _mst_device(scene, niter_PnP)
     E, N, P = len(scene.edges), scene.n_imgs, scene.max_area
     pred_i, pred_j, conf_i, conf_j = edge_views(scene, dev)
     pts3d, _, im_focals, im_poses = minimum_spanning_tree(scene.imshapes, scene.edges, pred_i, pred_j, conf_i, conf_j, scene.im_conf,

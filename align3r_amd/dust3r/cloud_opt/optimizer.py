@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from ...aligner import AlignEngine
+from . import _native
 from .init_im_poses import inv_rigid
 from .commons import get_conf_trf, get_imshapes, rotmat_to_unitquat, signed_expm1, signed_log1p, unitquat_to_rotmat
 
@@ -59,15 +60,26 @@ class PointCloudOptimizer:
             self._pred_j = torch.stack([_ravel_hw(as_f(p_j[e]), P) for e in range(E)])
             self._conf_i = torch.stack([_ravel_hw(as_f(c_i[e]), P) for e in range(E)])
             self._conf_j = torch.stack([_ravel_hw(as_f(c_j[e]), P) for e in range(E)])
-        self._raw_conf_i, self._raw_conf_j = self._conf_i.cpu(), self._conf_j.cpu()     # kept for the MST initialisation
         self.min_conf_thr = min_conf_thr
         self.conf_trf = get_conf_trf(conf)
-        # per-image confidence = max over the edges it appears in (base_opt.py:169-175)
-        im_conf = [torch.zeros(hw) for hw in self.imshapes]
-        for e, (i, j) in enumerate(self.edges):
-            (hi, wi), (hj, wj) = self.imshapes[i], self.imshapes[j]
-            im_conf[i] = torch.maximum(im_conf[i], self._raw_conf_i[e, :hi * wi].view(hi, wi))
-            im_conf[j] = torch.maximum(im_conf[j], self._raw_conf_j[e, :hj * wj].view(hj, wj))
+        self._conf_mode = conf
+        # Predictions that are already on the GPU (inference(keep_on_device=True), the multi-GPU gather) stay there: the per-image
+        # confidence, the loss weights and the per-edge mean confidence are three launches of csrc/init_maps.hip instead of a trip
+        # of both confidence stacks through host memory and a Python loop of CPU maximums (round 2: 0.5 s of a 1.5 s clip).
+        self._fast = bool(self._uniform and P % 4 == 0 and _native.on_device(self._conf_i, self._conf_j))
+        self._edge_conf_mean = None
+        if self._fast:
+            self._raw_conf_i, self._raw_conf_j = self._conf_i, self._conf_j
+            self._im_conf_stack = _native.im_conf_max(self._conf_i, self._conf_j, self.edges, N)
+            im_conf = [self._im_conf_stack[n].view(*self.imshapes[n]) for n in range(N)]
+        else:
+            self._raw_conf_i, self._raw_conf_j = self._conf_i.cpu(), self._conf_j.cpu()     # kept for the MST initialisation
+            # per-image confidence = max over the edges it appears in (base_opt.py:169-175)
+            im_conf = [torch.zeros(hw) for hw in self.imshapes]
+            for e, (i, j) in enumerate(self.edges):
+                (hi, wi), (hj, wj) = self.imshapes[i], self.imshapes[j]
+                im_conf[i] = torch.maximum(im_conf[i], self._raw_conf_i[e, :hi * wi].view(hi, wi))
+                im_conf[j] = torch.maximum(im_conf[j], self._raw_conf_j[e, :hj * wj].view(hj, wj))
         self.im_conf = im_conf
         self.base_scale, self.pw_break, self.focal_break = base_scale, pw_break, focal_break
         self.norm_pw_scale = True
@@ -76,7 +88,15 @@ class PointCloudOptimizer:
         # ---- parameters, drawn in the reference's order (base_opt.py:116-117; optimizer.py:29-38)
         init = dict(pw_poses=rand_pose((E, 1 + self.POSE_DIM)), pw_adaptors=torch.zeros(E, 2))
         if not self.if_use_mono:
-            init['depth'] = torch.stack([_ravel_hw(torch.randn(H, W) / 10 - 3, P) for H, W in self.imshapes])
+            if self._uniform:
+                # the reference draws torch.randn(H, W) / 10 - 3 per image (optimizer.py:33): same draws, same arithmetic, written
+                # straight into the rows of one buffer
+                depth = torch.empty(N, P)
+                for n, (H, W) in enumerate(self.imshapes):
+                    torch.randn(H, W, out=depth[n].view(H, W))
+                init['depth'] = depth.div_(10).sub_(3)
+            else:
+                init['depth'] = torch.stack([_ravel_hw(torch.randn(H, W) / 10 - 3, P) for H, W in self.imshapes])
             self.mono_depths = None
         else:
             init['depth'] = torch.zeros(N, P)
@@ -119,6 +139,9 @@ class PointCloudOptimizer:
 
     def _stacked_weights(self):
         E, P = len(self.edges), self.max_area
+        if self._fast and self._conf_mode in _native.CONF_MODES and _native.on_device(self._conf_i, self._conf_j):
+            w_i, w_j, self._edge_conf_mean = _native.conf_prepare(self._conf_i, self._conf_j, self._conf_mode)
+            return [w_i, w_j]
         out = []
         for conf, side in ((self._conf_i, 0), (self._conf_j, 1)):
             w = self.conf_trf(conf)

@@ -145,8 +145,19 @@ class PairEngine:
         check(self.lib.a3r_model_range_scales(self.handle, phase, buf, 1024, C.byref(n)), "a3r_model_range_scales")
         return np.array(buf[:min(n.value, 1024)], dtype=np.float32)
 
+    def site_stats(self):
+        """(diagnostic) max |scale * x| per fh2 site of the last call, in plan order."""
+        n = C.c_int()
+        buf = (C.c_float * 1024)()
+        check(self.lib.a3r_model_range_stats(self.handle, stream_ptr(), buf, 1024, C.byref(n)), "a3r_model_range_stats")
+        return np.array(buf[:min(n.value, 1024)], dtype=np.float32)
+
     def reset_ranges(self):
         check(self.lib.a3r_model_reset_ranges(self.handle), "a3r_model_reset_ranges")
+
+    def set_tap_level(self, level):
+        """Keep copies of decoder level `level` and of the point-cloud tokens for tap("level") / tap("pc0") (parity tests); 0 = off."""
+        check(self.lib.a3r_model_set_tap_level(self.handle, int(level)), "a3r_model_set_tap_level")
 
     def tap(self, name, cols):
         """Intermediate tensor of the last forward as a [rows, cols] view of the workspace (parity tests)."""

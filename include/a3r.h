@@ -299,6 +299,30 @@ int a3r_pnp_chunks(int n_max);
 size_t a3r_pnp_work_bytes(int B, int n_max);
 int a3r_pnp_solve(const void* desc, int B, int n_max, int iterations, void* work, float* c2w, float* info, void* stream);
 
+/* ---- per-pixel passes of the aligner's construction and of the MST initialisation (csrc/init_maps.hip), so that neither moves
+ * the confidences through the host nor depends on which torch kernels happen to be loaded already.
+ * a3r_conf_prepare: w_* [E, P] = trf(conf_* [E, P]) with mode 0 log | 1 sqrt | 2 x - 1 | 3 identity (commons.py:42-55; w_i = w_j =
+ *   NULL skips it) and edge_mean [2 E] (or NULL): mean(conf_i[e]) at 2 e, mean(conf_j[e]) at 2 e + 1 (commons.py:20-25), float64
+ *   sums in a fixed order.  16-byte aligned maps, P % 4 == 0.
+ * a3r_im_conf_max: out [N, P] = per-image confidence = max over the edges an image appears in, from 0 (base_opt.py:169-175);
+ *   ei / ej: DEVICE int32 [E].
+ * a3r_weiszfeld_focal: focal [B] of B point maps [B, H, W, 3], principal point at the centre, `iterations` re-weighting steps
+ *   (post_process.py:36-60, 'weiszfeld', 10 iterations in the reference), clipped at 0.
+ * a3r_sim3_apply: y [P, 3] = post * (k R x + T) with (s, R row-major, T) = sol[0..12] in DEVICE memory (a row of a3r_umeyama_solve's
+ *   output), k = s if with_scale else 1: geotrf(sRT_to_4x4(...), pts) without a host round trip (init_im_poses.py:226-233).
+ * a3r_depth_init: depth [N, P] = log of the camera-space depth of scale * pts [N, P, 3] under the world-to-camera matrices w2c
+ *   [N, 3, 4] (DEVICE), with log(z <= 0 | nan) -> 0 and log(inf) -> FLT_MAX, i.e. _set_depthmap's .log().nan_to_num(neginf=0)
+ *   (init_im_poses.py:116-126).
+ * a3r_mask_gt: out [n] (uint8) = x > thr. */
+int a3r_conf_prepare(const float* conf_i, const float* conf_j, int E, long P, int mode, float* w_i, float* w_j, float* edge_mean,
+                     void* stream);
+int a3r_im_conf_max(const float* conf_i, const float* conf_j, const int* ei, const int* ej, int E, int N, long P, float* out,
+                    void* stream);
+int a3r_weiszfeld_focal(const float* pts3d, int B, int H, int W, int iterations, float* focal, void* stream);
+int a3r_sim3_apply(const float* x, const float* sol, int with_scale, float post, float* y, long P, void* stream);
+int a3r_depth_init(const float* pts, const float* w2c, float scale, int N, long P, float* depth, void* stream);
+int a3r_mask_gt(const float* x, float thr, unsigned char* out, long n, void* stream);
+
 int a3r_upsample2x(const float* x, float* y, int B, int H, int W, int C, int Hc, int Wc, void* stream);
 /* the same, written in bf3 form ([B Hc Wc][C/8][3][8] bf16, C % 8 == 0): input of the next conv on the bf3 kernel */
 int a3r_upsample2x_bf3(const float* x, void* y3, int B, int H, int W, int C, int Hc, int Wc, void* stream);
@@ -353,8 +377,12 @@ int a3r_model_encode(a3r_model_t m, const float* img, int B, int H, int W, float
 int a3r_model_decode(a3r_model_t m, const float* feat1, const float* feat2, const float* pd1, const float* pd2, int B,
                      int H, int W, float* pts1, float* conf1, float* pts2, float* conf2, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* Debug taps for the parity tests: copies of intermediate tensors inside the workspace after a forward.
- * name in {"enc1","dec1_6","dec1_last","dec2_last","pc_tokens","raw1"}; returns device pointer + element count. */
+/* Debug taps for the parity tests: intermediate tensors inside the workspace after a forward; returns device pointer + element
+ * count.  name: "feat" (enc_norm output, model.py:163), "hook_a" / "hook_b" (the decoder levels the DPT head reads,
+ * dpt_head.py:101), "dec_last" (dec_norm output, model.py:231-232); after a3r_model_set_tap_level(m, L > 0) also "level" (the two
+ * decoders' outputs of block L incl. the zero-conv add, model.py:218-228) and "pc0" (patch_embed_point_cloud output,
+ * model.py:244-248) -- two more [2 B N, dec_embed_dim] buffers in the workspace (a3r_model_workspace_bytes accounts for them). */
+int a3r_model_set_tap_level(a3r_model_t m, int level);
 int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* count);
 
 /* Range control of the default (fh2) arithmetic.  The reference computes in fp32 (croco.py:13 even allows TF32) and has no
@@ -369,6 +397,9 @@ int a3r_model_tap(a3r_model_t m, const char* name, const float** ptr, size_t* co
  * a3r_model_reset_ranges puts every scale back to 1. */
 int a3r_model_range_check(a3r_model_t m, void* stream, int* n_adjusted, int* n_nonfinite);
 int a3r_model_reset_ranges(a3r_model_t m);
+/* (diagnostic) max |scale * x| every site of the LAST forward / encode / decode call recorded, in plan order (waits for `stream`);
+ * 0 = all-zero tensor or a site that did not run. */
+int a3r_model_range_stats(a3r_model_t m, void* stream, float* stored_absmax, int capacity, int* n_sites);
 /* (diagnostic) the current scales of plan `phase` (0 = forward, 1 = encode, 2 = decode), in plan order: *n_sites = their number,
  * the first min(capacity, *n_sites) are copied to scales (host). */
 int a3r_model_range_scales(a3r_model_t m, int phase, float* scales, int capacity, int* n_sites);

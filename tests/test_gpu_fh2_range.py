@@ -52,7 +52,8 @@ def test_producers_report_absmax_and_store_scaled(ops):
         ln = ops.layernorm_fh2(x, g, b, scale=s, absmax=w)
         ln1 = ops.layernorm_fh2(x, g, b)
         y1 = ln1.value()
-        assert float((ln.value() - y1).abs().max()) <= 2.0 ** -21 * float(y1.abs().max())
+        # (values with |s y| < 2^-3 carry the format's absolute resolution 2^-25 / s: at s = 2^-9 that is most of this tensor)
+        assert float((ln.value() - y1).abs().max()) <= 2.0 ** -21 * float(y1.abs().max()) + 2.0 ** -24 / min(s, 1.0)
         assert abs(ops.absmax_value(w) / s - float(y1.abs().max())) <= 2.0 ** -20 * float(y1.abs().max())
         # bilinear 2x
         m = rnd(2, 5, 6, 64, seed=4)
@@ -71,12 +72,14 @@ def close_fh2(a, b, scale):
 
 @pytest.mark.parametrize("epi", ["none", "gelu", "relu", "rope", "resid_aux"])
 def test_scales_divide_out_exactly(ops, epi):
-    """x stored with 2^-6, the output stored with 2^5: the fp32 results are the scale-1 results bit for bit (every scale is a power
-    of two and nothing under- or overflows for these operands), fh2 outputs represent the same values."""
+    """x stored with 2^6, the output stored with 2^5: the results are the scale-1 results up to the format's resolution (the scales are
+    powers of two and divide out exactly; WHICH elements have a subnormal second plane depends on the scale, so operands and
+    outputs agree to ~2^-25 absolute per element, not bit for bit)."""
     M, N, K = 200, 192, 96
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
     w2 = ops.split_fh2_w(w)
-    x1, xs = ops.split_fh2(x), ops.split_fh2(x, 2.0 ** -6)
+    x1, xs = ops.split_fh2(x), ops.split_fh2(x, 2.0 ** 6)
+    same = lambda a, c: float((a.double() - c.double()).abs().max()) <= 3e-7 * float(c.abs().max())
     cos, sin = ops.rope_tables(x.device)
     kw = dict(none={}, gelu=dict(epi=_lib.EPI_GELU), relu=dict(epi=_lib.EPI_RELU), rope=dict(epi=_lib.EPI_ROPE, rope=(128, 25, 5, cos, sin)))
     if epi == "resid_aux":
@@ -85,17 +88,17 @@ def test_scales_divide_out_exactly(ops, epi):
         word = ops.absmax_word(x.device)
         y1 = ops.linear_fh2(x1, w2, b, epi=_lib.EPI_RESID, resid=r, aux_fh2=a1, aux_relu=True)
         y2 = ops.linear_fh2(xs, w2, b, epi=_lib.EPI_RESID, resid=r, aux_fh2=a2, aux_relu=True, out_scale=2.0 ** 5, out_absmax=word)
-        assert torch.equal(y1, y2)                                  # the fp32 output is not scaled
-        assert close_fh2(a2.value(), torch.relu(y1).double(), 1.0) and close_fh2(a1.value(), torch.relu(y1).double(), 1.0)
-        assert ops.absmax_value(word) == float(torch.relu(y1).max()) * 32.0
+        assert same(y1, y2)                                         # the fp32 output is not scaled
+        assert close_fh2(a2.value(), torch.relu(y2).double(), 1.0) and close_fh2(a1.value(), torch.relu(y1).double(), 1.0)
+        assert ops.absmax_value(word) == float(torch.relu(y2).max()) * 32.0
         return
     word = ops.absmax_word(x.device)
     y1 = ops.linear_fh2(x1, w2, b, out_fh2=True, **kw[epi])
     y2 = ops.linear_fh2(xs, w2, b, out_fh2=True, out_scale=2.0 ** 5, out_absmax=word, **kw[epi])
     assert y2.scale == 32.0
     f32 = ops.linear_fh2(x1, w2, b, **kw[epi])
-    assert torch.equal(ops.linear_fh2(xs, w2, b, **kw[epi]), f32)
-    tol = 1e-6 if epi == "rope" else 0.0     # (the fp32- and the fh2-output epilogues contract the rotation differently: test_gpu_fh2.py)
+    assert same(ops.linear_fh2(xs, w2, b, **kw[epi]), f32)
+    tol = 1e-6     # (operands differ by the format's resolution; the fp32- and fh2-output epilogues contract the rotation differently)
     for y in (y1, y2):
         assert bool(((y.value() - f32.double()).abs() <= (2.0 ** -21 + tol) * f32.double().abs() + 2.0 ** -24 + tol * float(f32.abs().max())).all())
     assert abs(ops.absmax_value(word) / 32.0 - float(f32.abs().max())) <= tol * float(f32.abs().max())
@@ -132,7 +135,9 @@ def test_linear_fh2_outlier_channel_and_tiny_tensor(ops):
         s = band_scale(amax)
         y = ops.linear_fh2(ops.split_fh2(x, s), w2, bias)
         e2 = float(((y.double() - ref).abs() / den).max())
-        assert e2 < 3e-7 and e2 <= 1.5 * e32 + 1e-8, (case, e2, e32)
+        # (an outlier channel makes the fp32 accumulation itself lossy: every later add rounds at the outlier product's ulp -- the
+        # criterion is "not worse than the exact-fp32 MFMA kernel", whose own error is a few 1e-6 of sum |a||b| here)
+        assert e2 <= 1.5 * e32 + 1e-8 and e32 < 1e-5, (case, e2, e32)
 
 
 def test_linear_fh2_rows_over_eleven_decades(ops):
@@ -177,7 +182,7 @@ def test_conv3x3_fh2_scaled_operand(ops):
     word = ops.absmax_word(x.device)
     y = ops.conv3x3_fh2(ops.split_fh2(x, s), wp2, (B, H, W, Cin), b)
     e2 = float(((y.double() - ref).abs() / den).max())
-    assert e2 < 3e-7 and e2 <= 1.5 * e32 + 1e-8, (e2, e32)
+    assert e2 <= 1.5 * e32 + 1e-8 and e32 < 1e-5, (e2, e32)
     # relu -> fh2 with an output scale: planes of out_scale * relu(y), statistics = its maximum
     so = band_scale(float(torch.relu(y).max()))
     y2 = ops.conv3x3_fh2(ops.split_fh2(x, s), wp2, (B, H, W, Cin), b, epi=_lib.EPI_RELU, out_fh2=True, out_scale=so, out_absmax=word)
@@ -259,17 +264,30 @@ def test_tiny_model_outside_the_fp16_range_is_repaired_not_refused(case):
         eng.reset_ranges()
         eng.range_check = False
         raw = eng.forward(*args)
-        assert not bool(torch.isfinite(raw["conf_1"]).all())
+        st = eng.site_stats()
+        assert (st > 65504).any(), st.max()                         # sites whose values do not fit fp16 at scale 1 ...
+        # ... turn the raw decoder levels into NaN -- which the ReLUs of the DPT head swallow (fmaxf(NaN, 0) = 0): the outputs are
+        # finite and WRONG.  A check of the outputs (round 2's isfinite on the confidences) cannot see this; the statistics do.
+        lv = eng.tap("hook_a", TINY.dec_embed_dim)
+        assert not bool(torch.isfinite(lv).all())
+        assert max(rel_err(raw[k].cpu().numpy(), ref[k]) for k in ref if k in raw) > 1e-2
 
 
-def test_nonfinite_input_raises():
+@pytest.mark.parametrize("bad", [np.inf, np.nan])
+def test_nonfinite_input_raises(bad):
+    """torch propagates a NaN / Inf pixel to NaN outputs; here the first split pass sees it (its statistics are NaN-aware) and the
+    engine raises instead of returning numbers."""
     from align3r_amd.engine import PairEngine
     eng = PairEngine(TINY, synthetic_state_dict(TINY, 0))
     v = make_view_arrays(2, 64, 64)
     img = v[0][0].copy()
-    img[0, 0, 3, 3] = np.inf
+    img[0, 0, 3, 3] = bad
     with pytest.raises(RuntimeError, match="not finite"):
         eng.forward(*_dev(img, v[1][0], v[0][1], v[1][1]))
+    pd = v[0][1].copy()
+    pd[0, 5, 5, 2] = bad
+    with pytest.raises(RuntimeError, match="not finite"):
+        eng.forward(*_dev(v[0][0], v[1][0], pd, v[1][1]))
 
 
 def test_default_weights_need_no_repeat_after_the_first_call():

@@ -8,7 +8,7 @@ so (b) is the stricter statement for typical points.  What fp32 arithmetic deliv
 where the predicted distance d -> 0, so a handful of near-origin pixels of pts3d (view 1's own frame) differ by a few 1e-4
 between ANY two fp32 evaluation orders -- the numpy oracle against the reference's own CPU output shows (max 1.2e-4, p99.9 6e-5)
 on the same golden (tests/test_oracle_model.py) where the HIP engine shows (max 1.6e-4, p99.9 1.1e-4).  Asserted: 99 % of the
-points within 1e-4, 99.9 % within 2e-4, every point within 2e-3; confidences and pts3d_in_other_view within 1e-4 everywhere.
+points within 1e-4, 99.9 % within 2e-4, every point within 1.4e-3 (frozen at twice the worst value measured in round 2); confidences and pts3d_in_other_view within 1e-4 everywhere.
 The measured margins are printed by every test ([parity-margin] lines) and listed in DESIGN.md section 2."""
 import json
 import os
@@ -22,7 +22,9 @@ from align3r_amd.weights import TINY, VITL, synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-PT_TOL = (2e-3, 2e-4, 1e-4)      # per-point relative error of a point map: (max over pixels, 99.9th, 99th percentile)
+# per-point relative error of a point map: (max over pixels, 99.9th, 99th percentile).  Frozen in round 3 at <= 2x the largest values
+# measured in round 2 (profiles/r02_parity_margins.json: max 7.1e-4 vs the oracle at 512x384, p99.9 9.7e-5, p99 4.0e-5) -- not re-fitted
+PT_TOL = (1.4e-3, 2e-4, 1e-4)
 CONF_TOL = (1e-4, 1e-4, 1e-4)    # per-element relative error of a confidence map
 
 
@@ -53,10 +55,21 @@ def test_tiny_vs_reference_golden(tiny_engine, tag, H, W):
     # both pairs of the symmetrised graph in ONE batch: [(1,0), (0,1)]
     img1, img2 = np.concatenate([v[1][0], v[0][0]]), np.concatenate([v[0][0], v[1][0]])
     pd1, pd2 = np.concatenate([v[1][1], v[0][1]]), np.concatenate([v[0][1], v[1][1]])
-    r = tiny_engine.forward(*to_dev(img1, img2, pd1, pd2))
+    tiny_engine.set_tap_level(6)
+    try:
+        r = tiny_engine.forward(*to_dev(img1, img2, pd1, pd2))
+    finally:
+        tiny_engine.set_tap_level(0)
     B, N = 2, (H // 16) * (W // 16)
     feat = host(tiny_engine.tap("feat", TINY.enc_embed_dim)).reshape(2, B, N, -1)
     assert rel_err(feat[0, :1], t[f"{tag}_enc1"]) < TOL
+    # rows a-7 / a-8 directly: the point-cloud patch embedding (model.py:244-248) and decoder 1's level 6 -- six DecoderBlocks,
+    # decoder_embed, the zero-conv adds of the four dec_blocks_pc (model.py:201-228) -- against the reference's own tensors
+    pc0 = host(tiny_engine.tap("pc0", TINY.dec_embed_dim)).reshape(2, B, N, -1)
+    lvl = host(tiny_engine.tap("level", TINY.dec_embed_dim)).reshape(2, B, N, -1)
+    e_pc, e_l6 = rel_err(pc0[:, 0], t[f"{tag}_pc_tokens"]), rel_err(lvl[0, :1], t[f"{tag}_dec1_6"])
+    record_margin(f"tiny_{tag}_taps_vs_reference", pc_tokens=e_pc, dec1_level6=e_l6)
+    assert e_pc < TOL and e_l6 < TOL, (e_pc, e_l6)
     last = host(tiny_engine.tap("dec_last", TINY.dec_embed_dim)).reshape(2, B, N, -1)
     assert rel_err(last[0, :1], t[f"{tag}_dec1_last"]) < TOL
     assert rel_err(last[1, :1], t[f"{tag}_dec2_last"]) < TOL
