@@ -181,18 +181,25 @@ class AsymmetricCroCo3DStereo:
         self._ensure_params()
         return iter(self._params.values())
 
-    def __call__(self, view1, view2):
-        return self.forward(view1, view2)
+    def __call__(self, view1, view2, out=None):
+        return self.forward(view1, view2, out=out)
 
     # ------------------------------------------------------------------ forward (model.py:241-257)
-    def forward(self, view1, view2):
+    def forward(self, view1, view2, out=None):
+        """out (extension): dict(pts3d_1 [B,H,W,3], conf_1 [B,H,W], pts3d_2, conf_2) of contiguous float32 device tensors the engine
+        writes its results into -- e.g. this rank's rows of the gathered aligner buffers (parallel.sharded_inference)."""
+        img1, img2 = view1['img'], view2['img']
+        if img1.shape[-2:] != img2.shape[-2:]:
+            # The encoder of the reference still takes the two sizes apart (model.py:171-173, inherited from DUSt3R), but its
+            # forward then concatenates the two views' point maps along the batch axis (model.py:248, the Align3R addition), which
+            # torch.cat refuses for different H x W: the reference cannot run such a pair either.  Same exception type, its message.
+            raise RuntimeError(f'Sizes of tensors must match except in dimension 0. Expected size {img1.shape[-2]}x{img1.shape[-1]} but got '
+                               f'size {img2.shape[-2]}x{img2.shape[-1]} (the two views of a pair must have one image size: the '
+                               'reference concatenates their point maps, dust3r/model.py:248)')
         if self._engine is None:
             raise RuntimeError('AsymmetricCroCo3DStereo.forward: the model is not on a HIP device -- call .to("cuda"); '
                                'this build has no CPU compute path')
         dev = self.device
-        img1, img2 = view1['img'], view2['img']
-        if img1.shape[-2:] != img2.shape[-2:]:
-            raise NotImplementedError('pairs with two different image sizes (model.py:171-173) are not supported')
         B, _, H, W = img1.shape
         for v in (view1, view2):       # utils/misc.py:61: all true_shape identical when landscape_only=False
             ts = v.get('true_shape')
@@ -203,7 +210,7 @@ class AsymmetricCroCo3DStereo:
         if self.landscape_only:
             assert W >= H, f'img should be in landscape mode, but got {W=} {H=}'
         f = lambda t: t.to(dev, torch.float32).contiguous()
-        out = self._engine.forward(f(img1), f(img2), f(view1['pred_depth']), f(view2['pred_depth']))
+        out = self._engine.forward(f(img1), f(img2), f(view1['pred_depth']), f(view2['pred_depth']), out=out)
         res1 = dict(pts3d=out['pts3d_1'], conf=out['conf_1'], pred_mask=0)
         res2 = dict(pts3d_in_other_view=out['pts3d_2'], conf=out['conf_2'], pred_mask=0)
         return res1, res2

@@ -56,3 +56,25 @@ def test_rccl_gather_and_aligner_handover(model):  # noqa: F811
         assert torch.allclose(scene.get_im_poses(), scene_ref.get_im_poses(), rtol=1e-4, atol=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_self_launch_path():
+    """`python bench.py --gpus N` from a bare shell starts its own ranks through torch.distributed.run before anything touches the
+    GPU (bench.py:self_launch) -- the path the driver's 8-GPU run takes.  Rehearsed here with one rank as a FRESH child process:
+    the launcher, the RCCL process group, the sentinel check of the in-place all-gather and one timed step must produce the JSON
+    line with rccl_ranks == 1."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, A3R_BENCH_SELF_LAUNCH="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "4",
+                        "--frames", "4", "--no-cpu-baseline", "--no-align", "--no-cache-run", "--no-clip-run"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 1 and res["rccl_ranks"] == 1 and res["value"] > 0

@@ -280,3 +280,97 @@ def test_pnp_on_device():
     cands = pnp_focal_candidates(H, W)
     below, above = max(c for c in cands if c <= f), min(c for c in cands if c >= f)
     assert res[2] is not None and (res[2][0] == pytest.approx(below, rel=1e-6) or res[2][0] == pytest.approx(above, rel=1e-6))
+
+
+def test_init_map_kernels():
+    """csrc/init_maps.hip against the torch formulas they replace: conf_trf + per-edge mean (commons.py:20-25,42-55), per-image
+    confidence maximum (base_opt.py:169-175), Weiszfeld focal (post_process.py:36-60), geotrf of a similarity
+    (init_im_poses.py:226-233), _set_depthmap's log / nan_to_num (init_im_poses.py:116-126), conf > thr."""
+    from align3r_amd.dust3r.cloud_opt import _native
+    from align3r_amd.dust3r.cloud_opt.init_im_poses import estimate_focals
+    g = torch.Generator(device="cpu").manual_seed(5)
+    E, N, H, W = 6, 4, 24, 36
+    P = H * W
+    edges = [(0, 1), (1, 0), (1, 2), (2, 3), (3, 1), (0, 3)]
+    ci = (1 + 9 * torch.rand(E, P, generator=g)).cuda()
+    cj = (1 + 9 * torch.rand(E, P, generator=g)).cuda()
+    for mode, fn in (("log", torch.log), ("sqrt", torch.sqrt), ("m1", lambda x: x - 1), ("id", lambda x: x)):
+        wi, wj, mean = _native.conf_prepare(ci, cj, mode)
+        assert rel_err(cpu(wi), cpu(fn(ci))) < 1e-6 and rel_err(cpu(wj), cpu(fn(cj))) < 1e-6
+        ref_mean = torch.stack([ci.double().mean(1), cj.double().mean(1)], 1).reshape(-1)
+        assert rel_err(cpu(mean), cpu(ref_mean)) < 1e-6
+    imc = _native.im_conf_max(ci, cj, edges, N)
+    ref = torch.zeros(N, P).cuda()
+    for e, (i, j) in enumerate(edges):
+        ref[i] = torch.maximum(ref[i], ci[e])
+        ref[j] = torch.maximum(ref[j], cj[e])
+    assert torch.equal(imc, ref)
+    # point maps of a pinhole camera with focal f seeing a smooth surface (+ a few non-finite / zero-depth pixels)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    maps = []
+    for b, f in enumerate((30.0, 55.0, 41.5)):
+        d = 2 + 0.5 * torch.sin(xs / W * 4 + b) * torch.cos(ys / H * 3)
+        m = torch.stack(((xs - W / 2) / f * d, (ys - H / 2) / f * d, d), -1) + 0.01 * torch.randn(H, W, 3, generator=g)
+        m[0, 0, 2] = 0.0
+        maps.append(m)
+    maps = torch.stack(maps).cuda()
+    got = _native.weiszfeld_focal(maps).cpu().numpy()
+    want = np.asarray(estimate_focals(maps))
+    assert np.abs(got - want).max() < 2e-4 * want.max(), (got, want)
+    assert np.abs(got - [30.0, 55.0, 41.5]).max() < 1.5
+    # similarity read from device memory
+    sol = torch.tensor([1.7, 0.36, 0.48, -0.8, -0.8, 0.6, 0.0, 0.48, 0.64, 0.6, 0.3, -1.0, 2.0]).cuda()
+    x = rnd(P, 3, seed=9)
+    y = torch.empty_like(x)
+    R, T = sol[1:10].reshape(3, 3), sol[10:13]
+    _native.sim3_apply(x, sol, y)
+    assert rel_err(cpu(y), cpu(1.7 * (x @ R.T) + T)) < 1e-6
+    _native.sim3_apply(x, sol, y, with_scale=False, post=0.5)
+    assert rel_err(cpu(y), cpu(0.5 * ((x @ R.T) + T))) < 1e-6
+    # depth maps
+    pts = rnd(N, P, 3, seed=10) + torch.tensor([0.0, 0.0, 1.5]).cuda()
+    pts[0, 0] = torch.tensor([0.0, 0.0, float("inf")])
+    w2c = torch.eye(4)[:3].repeat(N, 1, 1).contiguous()
+    w2c[1, 2, 3] = 0.25
+    depth = torch.empty(N, P).cuda()
+    _native.depth_init(pts, w2c.cuda(), 0.8, depth)
+    z = (0.8 * pts[..., 2]) + w2c[:, 2, 3].cuda()[:, None]
+    want = z.log().nan_to_num(neginf=0)
+    assert bool((z <= 0).any()) and rel_err(cpu(depth), cpu(want)) < 1e-6
+    assert torch.equal(_native.mask_gt(ci, 5.0).bool(), ci > 5.0)
+
+
+def test_mst_fast_path_matches_generic_path():
+    """The device fast path of init='mst' (one image shape, predictions on the GPU: per-pixel passes as launches, pose algebra in
+    numpy) against the generic torch implementation of the same steps on the same scene: same tree, same poses / focals / depths
+    up to fp32 rounding.  (Both are the parity-unpinned restatement of init_im_poses.py:69-252; this pins them to each other.)"""
+    import bench
+    from align3r_amd.dust3r.cloud_opt import global_aligner
+    from align3r_amd.dust3r.image_pairs import make_pairs
+    H, W, N = 96, 128, 5
+    dev = torch.device("cuda:0")
+    views = [dict(idx=i, instance=str(i)) for i in range(N)]
+    edges = [(a["idx"], b["idx"]) for a, b in make_pairs(views, scene_graph="swin-2-noncyclic", symmetrize=True)]
+    E = len(edges)
+    P1 = torch.empty(E, H, W, 3, device=dev); C1 = torch.empty(E, H, W, device=dev)
+    P2 = torch.empty(E, H, W, 3, device=dev); C2 = torch.empty(E, H, W, device=dev)
+    for k, (i, j) in enumerate(edges):
+        p1, p2, cf = bench.synthetic_pair_geometry(i, j, H, W, dev)
+        P1[k], P2[k], C1[k], C2[k] = p1, p2, cf, cf
+    states = []
+    for fast in (True, False):
+        outp = dict(view1=dict(idx=[i for i, _ in edges]), view2=dict(idx=[j for _, j in edges]),
+                    pred1=dict(pts3d=P1, conf=C1), pred2=dict(pts3d_in_other_view=P2, conf=C2))
+        torch.manual_seed(0)
+        scene = global_aligner(outp, False, [], dev, verbose=False, min_conf_thr=3)
+        assert scene._fast
+        if not fast:
+            scene._fast = False
+            scene._raw_conf_i, scene._raw_conf_j = scene._raw_conf_i.cpu(), scene._raw_conf_j.cpu()
+            scene.im_conf = [c.cpu() for c in scene.im_conf]
+        scene.compute_global_alignment(init="mst", niter=0)
+        states.append({k: scene.engine.params[k].cpu().numpy().copy() for k in ("pw_poses", "depth", "im_poses", "im_focals")})
+        loss = float(scene())
+        assert loss < 0.05, loss
+    for k in states[0]:
+        assert rel_err(states[0][k], states[1][k]) < 2e-4, (k, rel_err(states[0][k], states[1][k]))

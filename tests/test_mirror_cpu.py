@@ -139,3 +139,16 @@ def test_pointcloud_optimizer_mixed_shapes_host_logic():
     assert np.array_equal(opt._init["depth"].numpy(), g[f"{tag}_init_im_depthmaps"])
     assert np.array_equal(opt._init["im_poses"].numpy(), g[f"{tag}_init_im_poses"])
     assert np.allclose(opt._init["im_focals"].numpy(), g[f"{tag}_init_im_focals"].ravel())
+
+
+def test_pair_with_two_image_sizes_fails_like_the_reference():
+    """The reference's encoder still separates two sizes (model.py:171-173) but its forward concatenates the two views' point maps
+    along the batch axis (model.py:248), which torch.cat refuses: a pair of two sizes is a RuntimeError there, and here."""
+    m = AsymmetricCroCo3DStereo(**tiny_kwargs())
+    v1 = dict(img=torch.zeros(1, 3, 64, 96), pred_depth=torch.zeros(1, 64, 96, 3))
+    v2 = dict(img=torch.zeros(1, 3, 48, 80), pred_depth=torch.zeros(1, 48, 80, 3))
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        m(v1, v2)
+    # the torch call the reference makes at model.py:248 on these views
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        torch.cat((v1["pred_depth"].permute(0, 3, 1, 2), v2["pred_depth"].permute(0, 3, 1, 2)), dim=0)
