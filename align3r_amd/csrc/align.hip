@@ -1106,6 +1106,13 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     A3R_CHECK_ARG(!s->train_adaptors || s->adam_pw_adaptors, "a3r_align_create: train_adaptors needs adam_pw_adaptors");
     A3R_CHECK_ARG(s->workspace && s->workspace_bytes >= need, "a3r_align_create: workspace too small (%zu < %zu)",
                   s->workspace_bytes, need);
+    {
+        // the per-chunk partial rows are addressed with 32-bit byte offsets from a buffer resource (store16_wt): both arrays must
+        // stay below 2 GiB (config 3: 2 * 4032 * 144 * 64 B = 74 MB)
+        const size_t nch = ((size_t)s->P + 1023) / 1024;
+        A3R_CHECK_ARG(2 * (size_t)s->E * nch * 64 < (1ull << 31) && (size_t)s->N * nch * 64 < (1ull << 31),
+                      "a3r_align_create: E * P / 1024 too large for the 32-bit partial-sum offsets (E=%d N=%d P=%d)", s->E, s->N, s->P);
+    }
     // edge indices must be dense 0..N-1 (base_opt.py:164-167)
     std::vector<int> deg(s->N + 1, 0), seen(s->N, 0);
     for (int e = 0; e < s->E; e++) {

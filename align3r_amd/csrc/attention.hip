@@ -185,10 +185,8 @@ extern "C" int a3r_attention(const float* q, int ldq, const float* k, int ldk, c
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
                     reinterpret_cast<uintptr_t>(o)) & 15) == 0, "a3r_attention: pointers must be 16-byte aligned");
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ATTN_LDS_BYTES));
-    }
+    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ATTN_LDS_BYTES); }));
     AttnArgs a = {q, k, v, o, ldq, ldk, ldv, ldo, B, H, Nq, Nk};
     const int nqb = (Nq + AQ - 1) / AQ, groups = B * H;
     dim3 grid(8 * ((groups + 7) / 8) * nqb);

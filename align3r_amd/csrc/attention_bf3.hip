@@ -266,11 +266,14 @@ static int attention_bf3_impl(const void* q3, int ldq, const void* k3, int ldk, 
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q3) | reinterpret_cast<uintptr_t>(k3) | reinterpret_cast<uintptr_t>(v3) |
                     reinterpret_cast<uintptr_t>(o3)) & 15) == 0, "a3r_attention_bf3: pointers must be 16-byte aligned");
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES));
-    }
+    A3R_HIP(attr_once.ensure([&] {
+        hipError_t e = hipSuccess;
+        const void* kerns[3] = {reinterpret_cast<const void*>(&attn_bf3_kernel<6>), reinterpret_cast<const void*>(&attn_bf3_kernel<3>),
+                                reinterpret_cast<const void*>(&attn_bf3_kernel<1>)};
+        for (const void* k : kerns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS_BYTES);
+        return e;
+    }));
     Attn3Args a = {static_cast<const char*>(q3), static_cast<const char*>(k3), static_cast<const char*>(v3), static_cast<char*>(o3),
                    (size_t)ldq * 6, (size_t)ldk * 6, (size_t)ldv * 6, (size_t)ldo * 6, B, H, Nq, Nk, ldo, out_pair ? 1 : 0, out_fh2 ? 1 : 0};
     const int nqb = (Nq + A3Q - 1) / A3Q, groups = B * H;

@@ -251,9 +251,7 @@ extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ld
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q2) | reinterpret_cast<uintptr_t>(k2) | reinterpret_cast<uintptr_t>(v2) |
                     reinterpret_cast<uintptr_t>(o2)) & 15) == 0, "a3r_attention_fh2: pointers must be 16-byte aligned");
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES));
-    }
+    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); }));
     Attn4Args a = {static_cast<const char*>(q2), static_cast<const char*>(k2), static_cast<const char*>(v2), static_cast<char*>(o2),
                    (size_t)ldq * 4, (size_t)ldk * 4, (size_t)ldv * 4, (size_t)ldo * 4, B, H, Nq, Nk,
                    0.125f * 1.4426950408889634f / (r.q_scale * r.k_scale), r.out_scale / r.v_scale, r.out_absmax};

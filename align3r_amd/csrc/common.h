@@ -51,17 +51,20 @@ struct ProfScope {
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the CURRENT DEVICE's function object: a process that builds engines
-// on several GPUs must opt in on each.  One atomic bit per device and call site; racing first launches on one device both set
-// the (idempotent) attribute.
+// on several GPUs must opt in on each.  One atomic bit per device and call site, set only AFTER the attribute call succeeded: a
+// second host thread racing the first launch on a device sees the bit clear and sets the (idempotent) attribute itself instead of
+// launching a kernel whose opt-in has not happened yet; a failed call is retried on the next launch.
 struct PerDeviceOnce {
     std::atomic<unsigned long long> done{0};
-    // true when the caller still has to run the per-device setup (and marks it done)
-    bool first(int* dev_out = nullptr) {
+    // runs `setup` (-> hipError_t) unless it already succeeded on the current device
+    template <class F> hipError_t ensure(F&& setup) {
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;     // unknown device: always set
-        if (dev_out) *dev_out = dev;
-        const unsigned long long bit = 1ull << dev;
-        return !(done.fetch_or(bit, std::memory_order_relaxed) & bit);
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        const unsigned long long bit = known ? 1ull << dev : 0;
+        if (known && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+        const hipError_t e = setup();
+        if (e == hipSuccess && known) done.fetch_or(bit, std::memory_order_release);
+        return e;
     }
 };
 

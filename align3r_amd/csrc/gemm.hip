@@ -163,9 +163,7 @@ static int launch_variant(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_kernel<AMODE, BM, BN, FULL, RELU_A>;
     constexpr int lds = 2 * (BM + BN) * LDP * 4;
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
+    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }));
     hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(256), lds, st, g);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -439,9 +439,7 @@ static int launch_bf3_variant(const GemmArgs& g, hipStream_t st) {
     constexpr int lds = NS * (BM + BN) * (3 * BK / 8) * 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
+    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }));
     hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(WM * WN * 64), lds, st, g);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
@@ -452,9 +450,7 @@ static int launch_bf3_w2h(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_bf3_w2h_kernel<FULL, NP>;
     constexpr int lds = 2 * 256 * 192 + 2 * 128 * 192;
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
+    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }));
     hipLaunchKernelGGL(kern, dim3(g.tiles_per_group * g.groups), dim3(512), lds, st, g);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -428,9 +428,7 @@ static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
     constexpr int ring = NS * (BM + BN) * 128, epi = WM * WN * epi_lds_wave_bytes(BM / WM), lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        A3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
+    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }));
     hipLaunchKernelGGL(kern, dim3(fa.g.tiles_per_group * fa.g.groups), dim3(WM * WN * 64), lds, st, fa);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -226,7 +226,8 @@ def linear_pnp_many(items, iterations=10):
         if not valid:
             continue
         if items[k][1] is not None:
-            out[k] = (float(f), c2w[b])
+            if inl > 0:                      # fast_pnp returns None when no pose scores an inlier (`if not best[0]: return None`, :480)
+                out[k] = (float(f), c2w[b])
         elif inl > 0 and (k not in best or (inl, -err) > best[k][0]):
             best[k] = ((inl, -err), b)
     for k, (_, b) in best.items():

@@ -158,6 +158,47 @@ def test_config2_full_size_vs_oracle(Engine):
     assert all(v < 1e-4 for k, v in margins.items() if k.startswith("state_")), margins
 
 
+def test_config3_full_size_vs_oracle(Engine):
+    """BASELINE config 3's alignment problem at FULL size on one GPU -- N = 64, complete graph (E = 4032), P = 288 x 512 = 147456:
+    19 GB of observations, 19.3 GB of HBM traffic per iteration -- against oracle/align_ref.c on the host: loss and every gradient
+    of the first evaluation, then 3 Adam steps.  (Sizes past 2^31 bytes per buffer: the 64-bit addressing of the kernels is what
+    this exercises; the 32-bit partial-sum offsets stay far below their limit, a3r_align_create checks it.)"""
+    from conftest import record_margin
+    from oracle.align_ref import AlignOracle
+    N, H, W = 64, 288, 512
+    edges = [(i, j) for i in range(N) for j in range(N) if i != j]
+    E, P = len(edges), H * W
+    assert E == 4032
+    rng = np.random.default_rng(33)
+    p1 = rng.standard_normal((E, P, 3), dtype=np.float32)
+    p2 = rng.standard_normal((E, P, 3), dtype=np.float32)
+    w1 = np.log1p(9 * rng.random((E, P), dtype=np.float32))
+    w2 = np.log1p(9 * rng.random((E, P), dtype=np.float32))
+    init = dict(pw_poses=rng.standard_normal((E, 8)).astype(np.float32), depth=(0.1 * rng.standard_normal((N, P)) - 3).astype(np.float32),
+                im_poses=rng.standard_normal((N, 7)).astype(np.float32), im_focals=np.full(N, 20 * np.log(max(H, W)), np.float32))
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(H, W)] * N)
+    o = AlignOracle(*args)
+    a = Engine(*args)
+    for eng in (o, a):
+        eng.set_params(**init)
+    lo, go = o.loss_grad()
+    la, ga = a.loss_grad()
+    margins = dict(loss0=abs(lo - la) / lo)
+    for k in go:
+        margins[f"grad_{k}"] = rel_err(host(ga[k]).reshape(go[k].shape), go[k])
+    lo = np.asarray(o.run(3, 0.05, "cosine"))
+    la = a.run(3, 0.05, "cosine")
+    margins["losses"] = rel_err(la, lo)
+    for k in o.trainable():
+        margins[f"state_{k}"] = rel_err(host(a.params[k]).reshape(o.params[k].shape), o.params[k])
+    record_margin("align_config3_full_size_vs_oracle", **margins)
+    del o, a, p1, p2, w1, w2
+    assert margins["loss0"] < 1e-6
+    assert all(v < 1e-5 for k, v in margins.items() if k.startswith("grad_")), margins
+    assert margins["losses"] < 1e-5 and la[-1] < la[0]
+    assert all(v < 1e-4 for k, v in margins.items() if k.startswith("state_")), margins
+
+
 def test_fused_tail_is_bitwise_the_launch_path(Engine, monkeypatch):
     """A3R_ALIGN_TAIL=fused finishes the iteration inside the main launch (two levels of last-block-done tickets, write-through
     partial rows, agent-scope acquire) instead of the two finalize launches.  Same sums in the same order: losses and every
