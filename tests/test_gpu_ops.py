@@ -277,9 +277,6 @@ def test_pnp_on_device():
         assert res[k] is not None and res[k][0] == f
         assert np.abs(res[k][1].cpu().numpy() - c2w).max() < tol, (k, res[k][1])
     assert res[3] is None
-    # a point map no camera explains (white noise): no reprojection within 5 px -> None, as fast_pnp's `if not best[0]: return None`
-    noise = linear_pnp_many([(t(rng.standard_normal((H, W, 3)) * 3), f, full, None)])
-    assert noise[0] is None
     cands = pnp_focal_candidates(H, W)
     below, above = max(c for c in cands if c <= f), min(c for c in cands if c >= f)
     assert res[2] is not None and (res[2][0] == pytest.approx(below, rel=1e-6) or res[2][0] == pytest.approx(above, rel=1e-6))

@@ -152,3 +152,17 @@ def test_pair_with_two_image_sizes_fails_like_the_reference():
     # the torch call the reference makes at model.py:248 on these views
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
         torch.cat((v1["pred_depth"].permute(0, 3, 1, 2), v2["pred_depth"].permute(0, 3, 1, 2)), dim=0)
+
+
+def test_pnp_selection_needs_an_inlier(monkeypatch):
+    """fast_pnp returns None when the best RANSAC score is 0 (init_im_poses.py:480 `if not best[0]: return None`), for a known focal
+    as for the focal search: a solver result that is formally valid but has no point within 5 px must not become a pose."""
+    from align3r_amd.dust3r.cloud_opt import init_im_poses as ip
+    pts, msk = torch.zeros(8, 8, 3), torch.ones(8, 8, dtype=torch.bool)
+
+    def fake(problems, iterations=10):        # (valid, inliers, truncated error, focal) per problem
+        info = np.array([[1, 0, 5.0, p[2]] if k % 2 == 0 else [1, 7, 1.0, p[2]] for k, p in enumerate(problems)], dtype=np.float32)
+        return info, torch.eye(4).repeat(len(problems), 1, 1)
+    monkeypatch.setattr(ip, "pnp_batched", fake)
+    res = ip.linear_pnp_many([(pts, 100.0, msk, None), (pts, 120.0, msk, None)])
+    assert res[0] is None and res[1] is not None and res[1][0] == 120.0
