@@ -94,6 +94,8 @@ def parse():
     ap.add_argument("--no-align", action="store_true")
     ap.add_argument("--no-cache-run", action="store_true", help="skip the extra encoder-cached measurement")
     ap.add_argument("--no-clip-run", action="store_true", help="skip the extra whole-clip wall clock (inference + init='mst' + 300 iterations)")
+    ap.add_argument("--no-bf16-run", action="store_true", help="skip the extra throughput figure of BASELINE config 5's plain-bf16 mode")
+    ap.add_argument("--no-align-config3", action="store_true", help="skip the extra aligner figure at BASELINE config 3's size (19 GB)")
     return ap.parse_args()
 
 
@@ -161,7 +163,8 @@ def main():
     pairs = make_pairs([dict(idx=i) for i in range(a.frames)], a.scene_graph, symmetrize=True)
     edges = [(p["idx"], q["idx"]) for p, q in pairs]
     E = len(edges)
-    eng = PairEngine(VITL, synthetic_state_dict(VITL, 0), dev)
+    sd = synthetic_state_dict(VITL, 0)
+    eng = PairEngine(VITL, sd, dev)
 
     def batch_inputs(step):
         idx = [edges[(step * B + k) % E] for k in range(B)]
@@ -336,6 +339,44 @@ def main():
         except Exception as ex:      # an extra must never take the headline down with it
             res["clip_wall_clock"] = {"error": f"{type(ex).__name__}: {ex}"}
 
+    # ---- extra (not the headline): BASELINE config 5's "bf16 MFMA path" -- A3R_GEMM=bf16, ONE bf16 x bf16 product per multiply
+    # (plain bf16 operands, fp32 accumulate), a reduced-precision mode that is never the default.  Same workload, same timed-region
+    # rules as the headline; its stated tolerances (asserted by tests/test_gpu_bf16_mode.py, frozen in round 2): tensor-max 5e-2,
+    # per-point p99 2e-1 against the fp32 oracle, ATE / extent 1e-2 and 6 degrees at pose level.
+    if not a.no_bf16_run and world == 1:
+        try:
+            prev = os.environ.get("A3R_GEMM")
+            os.environ["A3R_GEMM"] = "bf16"
+            try:
+                eng16 = PairEngine(VITL, sd, dev)       # the arithmetic mode is read when the handle is created
+            finally:
+                if prev is None:
+                    os.environ.pop("A3R_GEMM", None)
+                else:
+                    os.environ["A3R_GEMM"] = prev
+            eng16.forward(*inputs[0], out=out)
+            torch.cuda.synchronize()
+            _lib.prof_enable(True)
+            t0 = time.perf_counter()
+            n16 = 2
+            for s in range(n16):
+                eng16.forward(*inputs[s % n_batches], out=out)
+            torch.cuda.synchronize()
+            dt16 = time.perf_counter() - t0
+            _lib.prof_enable(False)
+            p16 = {p["name"]: p for p in _lib.prof_report()}
+            g16 = p16.get("gemm_bf3_kernel (linear, split-bf16 MFMA)")
+            res["bf16_mode"] = {"value": round(B * n16 / dt16, 3), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * dt16 / n16, 2),
+                                "gemm_tflops": round(g16["work"] / (g16["ms"] * 1e-3) / 1e12, 1) if g16 and g16["ms"] > 0 else None,
+                                "gemm_frac_of_bf16_peak": round(g16["work"] / (g16["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if g16 and g16["ms"] > 0 else None,
+                                "note": "A3R_GEMM=bf16 (BASELINE config 5's mode): one bf16 MFMA pass per product, fp32 accumulate -- REDUCED "
+                                        "precision (tolerances: tensor-max 5e-2, per-point p99 2e-1, ATE/extent 1e-2, rotation 6 deg; "
+                                        "tests/test_gpu_bf16_mode.py), never the default and not the headline value"}
+            del eng16
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            res["bf16_mode"] = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- global alignment (config 2: N=16, E=84, P=H*W), random-init state, its own timed region
     if not a.no_align:
         del eng, inputs
@@ -378,6 +419,44 @@ def main():
                                                "us_per_iter": round(1e6 * dta / a.align_iters, 2),
                                                "note": "whole iteration (main kernel + the two finalize launches + gaps), un-profiled wall clock"}}
         del al
+        # ---- extra: the aligner at BASELINE config 3's FULL size on one GPU (N = 64, complete graph, E = 4032, P = 288 x 512:
+        # 19 GB of observations, 19.3 GB of HBM traffic per iteration); parity of this problem: tests/test_gpu_align.py
+        if not a.no_align_config3 and world == 1:
+            try:
+                del pi, pj, wi, wj
+                torch.cuda.empty_cache()
+                N3, H3, W3 = 64, 288, 512
+                e3 = [(i, j) for i in range(N3) for j in range(N3) if i != j]
+                E3, P3 = len(e3), H3 * W3
+                gd = torch.Generator(device=dev).manual_seed(3)
+                al3 = AlignEngine([i for i, j in e3], [j for i, j in e3], torch.randn(E3, P3, 3, generator=gd, device=dev),
+                                  torch.randn(E3, P3, 3, generator=gd, device=dev),
+                                  torch.log(1 + 9 * torch.rand(E3, P3, generator=gd, device=dev)),
+                                  torch.log(1 + 9 * torch.rand(E3, P3, generator=gd, device=dev)), [(H3, W3)] * N3, device=dev, loss_capacity=128)
+                al3.set_params(pw_poses=torch.randn(E3, 8, generator=gd, device=dev), depth=torch.randn(N3, P3, generator=gd, device=dev) / 10 - 3,
+                               im_poses=torch.randn(N3, 7, generator=gd, device=dev), im_focals=torch.full((N3,), 20 * float(np.log(max(H3, W3)))))
+                al3.run(3, 0.05, "cosine", total_iters=43)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                al3.run(20, 0.05, "cosine", first_iter=3, total_iters=43)
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t0
+                _lib.prof_enable(True)
+                al3.run(20, 0.05, "cosine", first_iter=23, total_iters=43)
+                torch.cuda.synchronize()
+                _lib.prof_enable(False)
+                p3 = {p["name"]: p for p in _lib.prof_report()}["align_main_kernel"]
+                gbs3 = p3["work"] / (p3["ms"] * 1e-3) / 1e9
+                b3 = p3["work"] / max(p3["launches"], 1)
+                res["align_config3"] = {"iters_per_s": round(20 / dt3, 2), "N": N3, "E": E3, "P": P3, "bytes_per_iter": b3,
+                                        "main_kernel_us": round(1e3 * p3["ms"] / max(p3["launches"], 1), 1),
+                                        "main_kernel_gbs": round(gbs3, 1), "main_kernel_frac_of_hbm_peak": round(gbs3 / PEAK_HBM_GBS, 4),
+                                        "iteration_frac_of_hbm_peak": round(b3 * (20 / dt3) / 1e9 / PEAK_HBM_GBS, 4),
+                                        "note": "BASELINE config 3's alignment problem on ONE GPU (replica aligner, DESIGN section 6)"}
+                del al3
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                res["align_config3"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only, bounded sample)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -393,7 +472,11 @@ def main():
         res["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                "sample": f"1 pair {W}x{H} ViT-L through oracle/model_np.py (numpy + BLAS threads), {tc:.1f} s",
                                "note": "numpy port of the forward (GEMMs in the host BLAS, everything else single-threaded numpy): a reported baseline, "
-                                       "not an optimised CPU implementation; the aligner figure is the C/OpenMP oracle"}
+                                       "not an optimised CPU implementation; the aligner figure is the C/OpenMP oracle",
+                               "reference_torch_cpu": {"value": 0.188, "unit": "frame-pairs/s", "cores": 8, "align_iters_per_s": 0.57,
+                                                       "source": "SURVEY.md section 6: the reference's own torch CPU path, fp32, bs=1, 512x384, "
+                                                                 "measured in the 8-core build container (the reference cannot travel to the GPU "
+                                                                 "box); ~5x this port's rate per pair on 1/32 of the cores"}}
         if not a.no_align:
             rng = np.random.default_rng(2)
             o = AlignOracle([i for i, j in edges], [j for i, j in edges], rng.standard_normal((E, P, 3), dtype=np.float32),
