@@ -139,6 +139,7 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))      # host-side torch ops here are small: no 256-thread OpenMP teams
     # A3R_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, barrier, all-reduce) with a single rank too
     use_dist = world > 1 or os.environ.get("A3R_BENCH_FORCE_DIST") == "1" or os.environ.get("A3R_BENCH_SELF_LAUNCH") == "1"
     if use_dist:
@@ -381,16 +382,19 @@ def main():
     if not a.no_align:
         del eng, inputs
         torch.cuda.empty_cache()
-        g = torch.Generator(device="cpu").manual_seed(2)
+        # random scene drawn ON THE DEVICE: 100 M CPU randn wake every OpenMP worker of the host, and on a box whose CPU quota is a
+        # fraction of its cores (16 of 256 here) their spin-wait starves the thread that enqueues the iterations for the next
+        # ~200 ms -- exactly the timed region (measured: 434 us instead of 142 us per iteration with the same kernels)
+        g = torch.Generator(device=dev).manual_seed(2)
         N = a.frames
-        pi = torch.randn(E, P, 3, generator=g)
-        pj = torch.randn(E, P, 3, generator=g)
-        wi = torch.log(1 + 9 * torch.rand(E, P, generator=g))
-        wj = torch.log(1 + 9 * torch.rand(E, P, generator=g))
+        pi = torch.randn(E, P, 3, generator=g, device=dev)
+        pj = torch.randn(E, P, 3, generator=g, device=dev)
+        wi = torch.log(1 + 9 * torch.rand(E, P, generator=g, device=dev))
+        wj = torch.log(1 + 9 * torch.rand(E, P, generator=g, device=dev))
         al = AlignEngine([i for i, j in edges], [j for i, j in edges], pi, pj, wi, wj, [(H, W)] * N, device=dev,
                          loss_capacity=2 * a.align_iters + 16)
-        al.set_params(pw_poses=torch.randn(E, 8, generator=g), depth=torch.randn(N, P, generator=g) / 10 - 3,
-                      im_poses=torch.randn(N, 7, generator=g), im_focals=torch.full((N,), 20 * float(np.log(max(H, W)))))
+        al.set_params(pw_poses=torch.randn(E, 8, generator=g, device=dev), depth=torch.randn(N, P, generator=g, device=dev) / 10 - 3,
+                      im_poses=torch.randn(N, 7, generator=g, device=dev), im_focals=torch.full((N,), 20 * float(np.log(max(H, W)))))
         al.run(5, 0.05, "cosine", total_iters=2 * a.align_iters + 5)
         barrier()
         # (1) the iteration rate, un-profiled (the HIP events of the per-kernel profiler cost a few us per launch)
