@@ -21,7 +21,8 @@ class Epilogue(C.Structure):
                 ("rope_cols", C.c_int), ("tokens_per_image", C.c_int), ("grid_w", C.c_int), ("rope_cos", c_void),
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
                 ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int),
-                ("out_fh2", C.c_int), ("aux_fh2", c_void), ("x_scale", C.c_float), ("out_scale", C.c_float), ("out_absmax", c_void)]
+                ("out_fh2", C.c_int), ("aux_fh2", c_void), ("x_scale", C.c_float), ("out_scale", C.c_float), ("out_absmax", c_void),
+                ("head_w", c_void), ("head_b", c_void), ("head_conf", c_void)]
 
 
 class GroupPtrs(C.Structure):
@@ -65,7 +66,7 @@ class AlignFlowDesc(C.Structure):
                 ("dynamic_mask", c_void), ("workspace", c_void), ("workspace_bytes", C.c_size_t)]
 
 
-EPI_NONE, EPI_GELU, EPI_RESID, EPI_RELU, EPI_ROPE, EPI_RESID2, EPI_PIXSHUF = range(7)
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_RELU, EPI_ROPE, EPI_RESID2, EPI_PIXSHUF, EPI_HEAD = range(8)
 
 # name -> (restype, argtypes); every symbol declared in include/a3r.h
 SIGNATURES = {

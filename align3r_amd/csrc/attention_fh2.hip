@@ -230,7 +230,8 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
                 fh2_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v);
             }
     }
-    fh2_publish_absmax(a.out_absmax, amax);
+    __shared__ unsigned s_amax[A4T / 64];
+    fh2_publish_block(a.out_absmax, amax, s_amax);
 }
 
 }  // namespace a3r

@@ -121,9 +121,11 @@ __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restr
                                                              const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps,
                                                              float scale, unsigned* __restrict__ absmax) {
 #pragma clang fp contract(off)
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
     const int G = D >> 3;                                      // groups of 8 consecutive k in a row
+    float amax = 0.f;
+    // persistent rows loop (the grid is capped): the range statistics cost one atomic per workgroup, not one per row
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
     f32x4 v[VPL][2];
     float s = 0.f;
@@ -149,7 +151,6 @@ __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restr
     const f32x4* wr = reinterpret_cast<const f32x4*>(w);
     const f32x4* br = reinterpret_cast<const f32x4*>(b);
     char* yr = y2 + (size_t)row * fh2_row_bytes(D);
-    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         if (lane + 64 * i >= G) continue;
@@ -164,15 +165,18 @@ __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restr
         }
         fh2_store8(yr, (lane + 64 * i) * 8, o[0], o[1]);
     }
-    fh2_publish_absmax(absmax, amax);                          // (rows are per wave: every lane of a live wave arrives here)
+    }
+    __shared__ unsigned s_red[4];
+    fh2_publish_block(absmax, amax, s_red);
 }
 // any D % 32 == 0: lanes stride over the row's 8-k groups (three passes over an L1/L2-resident row)
 __global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                      const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps,
                                                                      float scale, unsigned* __restrict__ absmax) {
 #pragma clang fp contract(off)
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    float amax = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     const float* xr = x + (size_t)row * D;
     float s = 0.f;
     for (int i = lane; i < D; i += 64) s += xr[i];
@@ -181,7 +185,6 @@ __global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float*
     for (int i = lane; i < D; i += 64) { const float c = xr[i] - mean; ss += c * c; }
     const float rstd = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
     char* yr = y2 + (size_t)row * fh2_row_bytes(D);
-    float amax = 0.f;
     for (int k0 = lane * 8; k0 < D; k0 += 512) {
         f32x4 o[2];
 #pragma unroll
@@ -189,7 +192,9 @@ __global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float*
         amax = fh2_amax4(fh2_amax4(amax, o[0]), o[1]);
         fh2_store8(yr, k0, o[0], o[1]);
     }
-    fh2_publish_absmax(absmax, amax);
+    }
+    __shared__ unsigned s_red[4];
+    fh2_publish_block(absmax, amax, s_red);
 }
 
 // generic fallback (any D % 4 == 0; D % 8 == 0 for BF3): one wave per row, three passes over an L1/L2-resident row
@@ -318,7 +323,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
             fh2_store8(reinterpret_cast<char*>(y) + pix * ((size_t)C4 * 16), c * 4, lo, hi);
         } else yv[pix * C4 + c] = o[0];
     }
-    if (FMT == 2) fh2_publish_absmax(absmax, amax);
+    if (FMT == 2) {
+        __shared__ unsigned s_red[4];
+        fh2_publish_block(absmax, amax, s_red);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- head final
@@ -536,7 +544,8 @@ extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b,
     A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(y2) & 15) == 0, "a3r_layernorm_fh2: y2 must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PK_LAYERNORM, 8.0 * M * D, st);
-    dim3 grid((M + 3) / 4), block(256);
+    const int nblk = (M + 3) / 4;
+    dim3 grid(nblk < 4096 ? nblk : 4096), block(256);          // persistent rows loop: 16 workgroups per CU
     char* y = static_cast<char*>(y2);
     // rows up to 1536 wide stay in registers (one, two or three 8-k groups per lane; D = 768 uses two with the upper lanes idle in
     // the second: 2.7 -> 4.5+ TB/s against the three-pass generic kernel it used before)
@@ -636,7 +645,10 @@ extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W,
     A3R_CHECK_ARG(Hc > 0 && Hc <= 2 * H && Wc > 0 && Wc <= 2 * W, "a3r_upsample2x_fh2: crop window larger than the 2x map");
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
-    hipLaunchKernelGGL(upsample2x_kernel<2>, upsample_grid(B, Hc, Wc, C / 8), dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
+    dim3 grid = upsample_grid(B, Hc, Wc, C / 8);
+    const unsigned ycap = 8192 / grid.x > 1 ? 8192 / grid.x : 1;      // ~8 k workgroups: each loops over rows and publishes one statistics atomic
+    if (grid.y > ycap) grid.y = ycap;
+    hipLaunchKernelGGL(upsample2x_kernel<2>, grid, dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
                        C / 4, Hc, Wc, scale, absmax);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

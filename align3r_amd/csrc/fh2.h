@@ -67,30 +67,34 @@ __device__ __forceinline__ void fh2_store4(char* row, int k0, f32x4 v) {
 // ---- range statistics: running max |v| (v_max3_f32 with |.| source modifiers: half an instruction per element)
 __device__ __forceinline__ float fh2_amax2(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
 __device__ __forceinline__ float fh2_amax4(float m, f32x4 v) { return fh2_amax2(fh2_amax2(m, v.x, v.y), v.z, v.w); }
-// wave-wide max of m -> *slot (a non-negative float compared as an unsigned integer; Inf sorts above every finite value).  Call with
-// every lane of the wave active.  The plain read first: once the maximum is in, almost no wave issues the atomic.
-__device__ __forceinline__ void fh2_publish_absmax(unsigned* slot, float m) {
-    if (!slot) return;                                   // wave-uniform
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned b = __float_as_uint(m);
-        if (b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
+// Publishing the maximum: ONE fire-and-forget atomic per workgroup (per-wave butterfly -> LDS -> thread 0).  No read of the slot
+// first: a load whose result gates the atomic keeps every wave alive for an L2 round trip at its very end -- with one wave per
+// LayerNorm row that doubled the kernel's duration (round 3, measured).  Kernels keep their workgroup count in the low thousands
+// (persistent loops) so the atomics of a launch do not queue up on one address.  A non-negative float compares like its bit pattern;
+// Inf sorts above every finite value, NaN above Inf.  Every thread of the workgroup must call it.  s_red: blockDim / 64 words of LDS.
+__device__ __forceinline__ void fh2_publish_block(unsigned* slot, unsigned b, unsigned* s_red) {
+    if (!slot) return;                                   // uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = s_red[0];
+        for (unsigned w = 1; w < (blockDim.x >> 6); w++) m = max(m, s_red[w]);
+        if (m) atomicMax(slot, m);
     }
 }
+__device__ __forceinline__ void fh2_publish_block(unsigned* slot, float amax, unsigned* s_red) {
+    fh2_publish_block(slot, __float_as_uint(amax), s_red);
+}
 
-// NaN-aware variant for the HBM-bound producers that read MODEL INPUTS (split passes: images, point maps, weights): the maximum of
+// NaN-aware statistics for the HBM-bound producers that read MODEL INPUTS (split passes: images, point maps, weights): the maximum of
 // the bit patterns with the sign cleared, where NaN sorts above Inf -- v_max_f32 ignores a NaN operand, and a NaN that enters the
 // network can end as a finite number (fmaxf(NaN, 0) = 0 in a ReLU), so it must be caught where it enters.  Two VALU ops per element.
 __device__ __forceinline__ unsigned fh2_amax_bits4(unsigned m, f32x4 v) {
     const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
     const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
     return max(max(m, max(a, b)), max(c, d));
-}
-__device__ __forceinline__ void fh2_publish_absmax_bits(unsigned* slot, unsigned b) {
-    if (!slot) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
-    if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, b);
 }
 
 }  // namespace a3r

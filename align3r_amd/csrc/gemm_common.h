@@ -417,7 +417,10 @@ static inline int check_epilogue(const a3r_epilogue* e, int M, int N, const char
         A3R_CHECK_ARG(N % 8 == 0 && e->epi != A3R_EPI_PIXSHUF && (reinterpret_cast<uintptr_t>(e->aux_bf3) & 15) == 0,
                       "%s: aux_bf3 needs N %% 8 == 0, a 16-byte aligned buffer and no PIXSHUF", who);
     }
-    A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_PIXSHUF, "%s: unknown epilogue %d", who, e->epi);
+    A3R_CHECK_ARG(e->epi >= A3R_EPI_NONE && e->epi <= A3R_EPI_HEAD, "%s: unknown epilogue %d", who, e->epi);
+    if (e->epi == A3R_EPI_HEAD)
+        A3R_CHECK_ARG(fh2_kernel && N == 128 && e->head_w && e->head_b && e->head_conf && !e->out_fh2 && !e->aux_fh2 && !e->out_bf3 && !e->aux_bf3,
+                      "%s: the HEAD epilogue is available on the fh2 kernels for N == 128 with head_w, head_b, head_conf and no other output form", who);
     if (e->epi == A3R_EPI_ROPE)
         A3R_CHECK_ARG(e->rope_cols % 64 == 0 && e->rope_cols <= N && e->tokens_per_image > 0 && e->grid_w > 0 &&
                           e->tokens_per_image % e->grid_w == 0 && e->rope_cos && e->rope_sin,

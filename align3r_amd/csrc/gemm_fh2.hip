@@ -38,7 +38,6 @@ struct Fh2Args {
     GemmArgs g;
     float inv_wscale[4];      // per group: 1 / (w_scale x_scale), times out_scale for an out_fh2 output whose epilogue is homogeneous (not GELU)
     int gm;                   // row tiles per L2 block: workgroup ids walk gm row tiles before the next column tile (1 = row-major tile order)
-    int lab;                  // developer experiment (A3R_FH2_LAB): 1 = every tile LOADS operand tiles (m & 1, n & 1) -- all L2 hits
 };
 
 // all-zero source for the padding taps of the implicit conv (LDS-DMA has no predicated zero fill)
@@ -161,7 +160,60 @@ __device__ __forceinline__ void fh2_epilogue_out(const GemmArgs& g, const GroupP
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL, int LAB = 0, int AMODE = 0>
+// ---- A3R_EPI_HEAD: relu(acc + bias) of a [BM, 128] tile stays in registers; the 128 -> 4 projection is reduced over a lane's two
+// columns, the 16 lanes of a DPP row and the four column waves (through the idle stage ring, fixed order), then one thread per pixel
+// applies the postprocess (heads/postprocess.py:37-58) and stores 16 bytes instead of the 512 the tile would have taken
+template <int TM, bool FULL, int BM, int WM, int WN>
+__device__ __forceinline__ void fh2_epilogue_head(const GemmArgs& g, const GroupPtrs& P, f32x4 (&acc)[TM][2], int m0, int wm, int wn, int lane,
+                                                  char* smem) {
+    static_assert(WN * 32 == 128, "four column waves of 32");
+    const a3r_epilogue& ep = g.epi;
+    const int quad = lane >> 4, lcol = lane & 15;
+    float w4[4][2], bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = wn * 32 + j * 16 + lcol;
+        bias[j] = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; o++) w4[o][j] = ep.head_w[o * 128 + col];
+    }
+    __syncthreads();                                            // every wave is done reading the last stage: the ring is free
+    f32x4* part = reinterpret_cast<f32x4*>(smem);               // [BM rows][WN]
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float v = fmaxf(acc[i][j][e] + bias[j], 0.f);
+#pragma unroll
+                for (int o = 0; o < 4; o++) s[o] = __fmaf_rn(v, w4[o][j], s[o]);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) s[o] = dpp_row_sum16(s[o]);
+            if (lcol == 0) part[(wm * (TM * 16) + i * 16 + quad * 4 + e) * WN + wn] = f32x4{s[0], s[1], s[2], s[3]};
+        }
+    __syncthreads();
+    const float b0 = ep.head_b[0], b1 = ep.head_b[1], b2 = ep.head_b[2], b3 = ep.head_b[3];
+    for (int r = threadIdx.x; r < BM; r += WM * WN * 64) {
+        const long row = (long)m0 + r;
+        if (!FULL && row >= g.M) continue;
+        f32x4 t = part[r * WN];
+#pragma unroll
+        for (int w = 1; w < WN; w++) t += part[r * WN + w];
+        const float a0 = t.x + b0, a1 = t.y + b1, a2 = t.z + b2, a3 = t.w + b3;
+        // reference order: xyz / d.clip(1e-8) * expm1(d)   (postprocess.py:37-46)
+        const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+        const float dd = fmaxf(d, 1e-8f), em = expm1f(d);
+        P.C[row * 3 + 0] = a0 / dd * em;
+        P.C[row * 3 + 1] = a1 / dd * em;
+        P.C[row * 3 + 2] = a2 / dd * em;
+        ep.head_conf[row] = 1.f + expf(a3);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, int AMODE = 0>
 __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4) void gemm_fh2_kernel(Fh2Args fa) {
     const GemmArgs& g = fa.g;
     constexpr int NT = WM * WN * 64, U = 8;
@@ -205,8 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
 #pragma unroll
     for (int i = 0; i < LA; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
-        const int lm0 = fa.lab == 1 ? (tile_m & 1) * BM : m0;
-        const int gm = FULL ? lm0 + r : min(lm0 + r, g.M - 1);     // rows past M are computed on a copy of the last row, never stored
+        const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
         if (AMODE == 0) {
             srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + (j ^ fh2_swz(r)) * 16;
             tapsA[i] = 0;
@@ -228,8 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
 #pragma unroll
     for (int i = 0; i < LB; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
-        const int ln0 = fa.lab == 1 ? (tile_n & 1) * BN : n0;
-        const int gn = FULL ? ln0 + r : min(ln0 + r, g.N - 1);
+        const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
         srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + (j ^ fh2_swz(r)) * 16;
     }
     int c_tap = 0, c_ci = 0;                                          // AMODE 1: (tap, first channel) of the next stage to issue (stages are issued in order)
@@ -299,7 +349,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
             if (kt + NS <= nk) fh2_wait_vmcnt<(NS - 2) * LPS>();
             else fh2_wait_vmcnt_dyn((nk - kt - 2) * LPS);
             __builtin_amdgcn_s_barrier();
-            if (kt + NS < nk && LAB != 3 && LAB != 4 && (LAB != 5 || (wave >> 2) == 0)) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
+            if (kt + NS < nk) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -310,25 +360,19 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
         for (int i = 0; i < TM; i++) {
             // per accumulator the terms are added smallest first (x1 w0, x0 w1, x0 w0); across the row's accumulators the products of the
             // SECOND plane of A go first, so that plane's registers can be re-filled for the next stage four MFMAs earlier
-            if constexpr (LAB == 2 || LAB == 4) {
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j][0] += (float)af[i][1][0] + (float)bc[j][1][0] + (float)af[i][0][1] + (float)bc[j][0][1];
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
-                if constexpr (NEXT) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    af[i][1] = *reinterpret_cast<const f16x8*>(sb + offA[1] + i * 16 * U * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][1], bc[j][0], acc[i][j], 0, 0, 0);
             if constexpr (NEXT) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (LAB == 5 && i + 1 < 4 && (wave >> 2) == i + 1 && kt + NS < nk) issue(kt + NS, nbuf == 0 ? NS - 1 : nbuf - 1);
+                af[i][1] = *reinterpret_cast<const f16x8*>(sb + offA[1] + i * 16 * U * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
+            if constexpr (NEXT) {
+                __builtin_amdgcn_sched_barrier(0);
                 af[i][0] = *reinterpret_cast<const f16x8*>(sb + offA[0] + i * 16 * U * 16);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -353,6 +397,12 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = acc[i][j] * inv;
+    if constexpr (BN == 128 && WN == 4 && TN == 2) {
+        if (g.epi.epi == A3R_EPI_HEAD) {                       // wave-uniform
+            fh2_epilogue_head<TM, FULL, BM, WM, WN>(g, P, acc, m0, wm, wn, lane, smem);
+            return;
+        }
+    }
     // (the launch allocates max(stage ring, epilogue images) bytes of LDS)
     // the epilogues work on 32-column blocks of the wave tile
     const bool to_fh2 = g.epi.out_fh2, via_lds = !to_fh2 && epilogue16_lds_ok(g, P);       // wave-uniform
@@ -372,7 +422,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     if constexpr (TN >= 4) block(std::integral_constant<int, 1>{});
     if constexpr (TN >= 6) block(std::integral_constant<int, 2>{});
     if constexpr (TN >= 8) block(std::integral_constant<int, 3>{});
-    fh2_publish_absmax(P.out_absmax, amax);
+    {
+        __shared__ unsigned s_amax[WM * WN];
+        fh2_publish_block(P.out_absmax, amax, s_amax);
+    }
 }
 
 // fp32 [M, ldx] -> fh2 [M][K/8][2][8]: one thread per group of 8 consecutive k (32 B in, 32 contiguous bytes out)
@@ -388,14 +441,16 @@ __global__ __launch_bounds__(256) void split_fh2_kernel(const float* __restrict_
         amax = fh2_amax_bits4(fh2_amax_bits4(amax, lo), hi);
         fh2_store8(y + row * ((size_t)K8 * 32), kg * 8, lo, hi);
     }
-    fh2_publish_absmax_bits(absmax, amax);                  // every lane arrives here
+    __shared__ unsigned s_red[4];
+    fh2_publish_block(absmax, amax, s_red);                 // every thread arrives here
 }
 
 // max |x| of n floats -> *out (a non-negative float compared as an unsigned integer; *out must be zero before the launch)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
     unsigned m = 0;                                         // bit patterns with the sign cleared: a NaN weight sorts above everything
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
-    fh2_publish_absmax_bits(out, m);
+    __shared__ unsigned s_red[4];
+    fh2_publish_block(out, m, s_red);
 }
 
 struct Fh2Tile { int bm, bn, occ; double eff; };
@@ -422,9 +477,9 @@ static int choose_fh2_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL, int LAB = 0, int AMODE = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, int AMODE = 0>
 static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
-    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, LAB, AMODE>;
+    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, AMODE>;
     constexpr int ring = NS * (BM + BN) * 128, epi = WM * WN * epi_lds_wave_bytes(BM / WM), lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
@@ -438,10 +493,9 @@ template <int AMODE>
 static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     GemmArgs& g = fa.g;
     g.direct_epilogue = 0;
-    if (const char* l = getenv("A3R_FH2_LAB")) fa.lab = atoi(l);
     static const int gm_env = getenv("A3R_FH2_GM") ? atoi(getenv("A3R_FH2_GM")) : 0;
     int t = choose_fh2_tile(g.M, g.N, g.groups);
-    if (AMODE == 1 && t != 0) t = 2;                       // the implicit conv is built for tiles 0 and 2
+    if ((AMODE == 1 || g.epi.epi == A3R_EPI_HEAD) && t != 0) t = 2;   // the implicit conv and the HEAD epilogue are built for tiles 0 and 2
     const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -457,19 +511,9 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     const double a_bytes = AMODE == 1 ? 4.0 * (g.M / (g.cHo * g.cWo)) * g.cH * g.cW * g.cCin : 4.0 * g.M * g.K;
     ProfScope prof(AMODE == 1 ? PK_CONV_FH2 : PK_LINEAR_FH2, 2.0 * g.M * g.N * g.K * g.groups, st, g.groups * (a_bytes + 4.0 * g.N * g.K + c_bytes));
     if (t == 0) {
-#ifdef A3R_FH2_LABS                                        // component-isolation experiments (wrong results by design): make CXXFLAGS+=-DA3R_FH2_LABS
-        if (AMODE == 0 && full && fa.lab >= 2) {
-            switch (fa.lab) {
-                case 2: return launch_fh2_variant<256, 128, 4, 4, 3, true, 2>(fa, st);
-                case 3: return launch_fh2_variant<256, 128, 4, 4, 3, true, 3>(fa, st);
-                case 4: return launch_fh2_variant<256, 128, 4, 4, 3, true, 4>(fa, st);
-                case 5: return launch_fh2_variant<256, 128, 4, 4, 3, true, 5>(fa, st);
-            }
-        }
-#endif
-        return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, 0, AMODE>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, 0, AMODE>(fa, st);
+        return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, AMODE>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, AMODE>(fa, st);
     }
-    if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, 0, AMODE>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, 0, AMODE>(fa, st);
+    if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, AMODE>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, AMODE>(fa, st);
     if constexpr (AMODE == 0) {
         if (t == 3) return full ? launch_fh2_variant<256, 128, 4, 2, 3, true>(fa, st) : launch_fh2_variant<256, 128, 4, 2, 3, false>(fa, st);
         return full ? launch_fh2_variant<128, 64, 4, 2, 3, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false>(fa, st);
@@ -508,7 +552,8 @@ extern "C" int a3r_split_fh2(const float* x, int ldx, void* y, long M, int K, fl
     hipStream_t st = as_stream(stream);
     ProfScope prof(PK_SPLIT, 8.0 * M * K, st);
     const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(split_fh2_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, st, x, ldx,
+    // persistent grid (8 workgroups per CU): one statistics atomic per workgroup, see fh2_publish_block
+    hipLaunchKernelGGL(split_fh2_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, ldx,
                        static_cast<char*>(y), M, K / 8, scale, absmax);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -1046,6 +1046,7 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             P.conv3(a33, Hd.a3cw, l3, B, nh, nw, ld[3], ld[3], 2, e);
         }
         float* h2 = nullptr;
+        bool fused_tail = false;
         const int Hh = 8 * nh, Wh = 8 * nw;
         if (!P.bf3()) {
             // scratch.layer_rn (no bias)
@@ -1102,10 +1103,19 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
             P.conv3(p13, Hd.h0w, h0, B, Hh, Wh, F, F / 2, 1, P.epi(A3R_EPI_NONE, Hd.h0b));
             float* hu3 = P.alloc3((size_t)B * H * W, F / 2);
             P.up3(h0, hu3, B, Hh, Wh, F / 2, H, W);
-            h2 = ar.alloc((size_t)B * H * W * L);
-            P.conv3(hu3, Hd.h2w, h2, B, H, W, F / 2, L, 1, P.epi(A3R_EPI_RELU, Hd.h2b));
+            if (P.cf2() && L == 128) {
+                // head.2 (3x3 conv + ReLU), head.4 (1x1 conv 128 -> 4) and the postprocess in ONE launch: the [B H W, 128] map is
+                // neither written nor read back (8.4 GB per head and step at 42 pairs), dpt_block.py:323-329 + postprocess.py:10-58
+                a3r_epilogue e = P.epi(A3R_EPI_HEAD, Hd.h2b);
+                e.head_w = Hd.h4w; e.head_b = Hd.h4b; e.head_conf = s ? conf2 : conf1;
+                P.conv3(hu3, Hd.h2w, s ? pts2 : pts1, B, H, W, F / 2, L, 1, e);
+                fused_tail = true;
+            } else {
+                h2 = ar.alloc((size_t)B * H * W * L);
+                P.conv3(hu3, Hd.h2w, h2, B, H, W, F / 2, L, 1, P.epi(A3R_EPI_RELU, Hd.h2b));
+            }
         }
-        if (!P.skip())
+        if (!fused_tail && !P.skip())
             P.rc = a3r_head_final(h2, Hd.h4w, Hd.h4b, s ? pts2 : pts1, s ? conf2 : conf1, (long)B * H * W, L, stream);
     }
     if (peak) *peak = ar.peak;

@@ -78,7 +78,11 @@ enum {
     A3R_EPI_ROPE = 4,     /* y = rope2d(acc + bias) on the first rope_cols columns (heads of 64), rest plain:
                              fuses RoPE2D (pos_embed.py:141-157) into the q/k projections blocks.py:96-103,155-162 */
     A3R_EPI_RESID2 = 5,   /* y = resid + resid2 + acc + bias              RCU skip + fusion add dpt_block.py:142,198 */
-    A3R_EPI_PIXSHUF = 6   /* ConvTranspose2d(kernel=stride=s) scatter: row = input pixel, col = (dy,dx,co) */
+    A3R_EPI_PIXSHUF = 6,  /* ConvTranspose2d(kernel=stride=s) scatter: row = input pixel, col = (dy,dx,co) */
+    A3R_EPI_HEAD = 7      /* fh2 kernels, N == 128 only: the tail of the DPT head fused into its last 3x3 conv -- t = relu(acc + bias)
+                             [M, 128] never reaches memory; f = t @ head_w^T + head_b (Conv2d 1x1 128 -> 4, dpt_block.py:328) and the
+                             postprocess (heads/postprocess.py:10-58: pts3d = xyz / max(|xyz|, 1e-8) * expm1(|xyz|), conf = 1 + exp(f3))
+                             are done in the epilogue: y = pts3d [M, 3], head_conf = conf [M] */
 };
 
 typedef struct {
@@ -123,6 +127,10 @@ typedef struct {
      * point takes them per group (a3r_group_ptrs_fh2) and ignores these. */
     float x_scale, out_scale;
     unsigned* out_absmax;
+    /* A3R_EPI_HEAD */
+    const float* head_w;  /* [4, 128] */
+    const float* head_b;  /* [4] */
+    float* head_conf;     /* [M] */
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
