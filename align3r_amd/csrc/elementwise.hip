@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_pair_kernel(const float* __rest
 
 // fh2 output (fh2.h; scale 1): one wave per row, a lane owns 8 CONSECUTIVE k per step (two adjacent float4 loads), so it writes the
 // two planes' 16-byte units of its group -- 32 contiguous bytes per lane, 2 KB contiguous per wave and step.
-template <int VPL>   // 8-k groups per lane: D <= 512 VPL (D % 8 == 0); a lane whose group lies past the row contributes zeros and stores nothing
+template <int VPL, bool STATS>   // 8-k groups per lane: D <= 512 VPL (D % 8 == 0); a lane whose group lies past the row contributes zeros and stores nothing
 __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, char* __restrict__ y2, int M, int D, float eps,
                                                              float scale, unsigned* __restrict__ absmax) {
@@ -161,13 +161,15 @@ __global__ __launch_bounds__(256) void layernorm_fh2_kernel(const float* __restr
             const f32x4 t = v[i][h] * rstd, wv = wr[c], bv = br[c];
             o[h] = f32x4{__builtin_fmaf(t.x, wv.x, bv.x), __builtin_fmaf(t.y, wv.y, bv.y), __builtin_fmaf(t.z, wv.z, bv.z),
                          __builtin_fmaf(t.w, wv.w, bv.w)} * scale;
-            amax = fh2_amax4(amax, o[h]);
+            if (STATS) amax = fh2_amax4(amax, o[h]);
         }
         fh2_store8(yr, (lane + 64 * i) * 8, o[0], o[1]);
     }
     }
-    __shared__ unsigned s_red[4];
-    fh2_publish_block(absmax, amax, s_red);
+    if (STATS) {
+        __shared__ unsigned s_red[4];
+        fh2_publish_block(absmax, amax, s_red);
+    }
 }
 // any D % 32 == 0: lanes stride over the row's 8-k groups (three passes over an L1/L2-resident row)
 __global__ __launch_bounds__(256) void layernorm_fh2_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -545,14 +547,15 @@ extern "C" int a3r_layernorm_fh2(const float* x, const float* w, const float* b,
     hipStream_t st = as_stream(stream);
     ProfScope prof(PK_LAYERNORM, 8.0 * M * D, st);
     const int nblk = (M + 3) / 4;
-    dim3 grid(nblk < 4096 ? nblk : 4096), block(256);          // persistent rows loop: 16 workgroups per CU
+    // with statistics: a persistent rows loop (16 workgroups per CU, one atomic each); without: one row per wave
+    dim3 grid(absmax && nblk > 4096 ? 4096 : nblk), block(256);
     char* y = static_cast<char*>(y2);
     // rows up to 1536 wide stay in registers (one, two or three 8-k groups per lane; D = 768 uses two with the upper lanes idle in
     // the second: 2.7 -> 4.5+ TB/s against the three-pass generic kernel it used before)
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
-    if (aligned && D <= 512) hipLaunchKernelGGL(layernorm_fh2_kernel<1>, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
-    else if (aligned && D <= 1024) hipLaunchKernelGGL(layernorm_fh2_kernel<2>, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
-    else if (aligned && D <= 1536) hipLaunchKernelGGL(layernorm_fh2_kernel<3>, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
+    if (aligned && D <= 512) { if (absmax) hipLaunchKernelGGL((layernorm_fh2_kernel<1, true>), grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax); else hipLaunchKernelGGL((layernorm_fh2_kernel<1, false>), grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax); }
+    else if (aligned && D <= 1024) { if (absmax) hipLaunchKernelGGL((layernorm_fh2_kernel<2, true>), grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax); else hipLaunchKernelGGL((layernorm_fh2_kernel<2, false>), grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax); }
+    else if (aligned && D <= 1536) { if (absmax) hipLaunchKernelGGL((layernorm_fh2_kernel<3, true>), grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax); else hipLaunchKernelGGL((layernorm_fh2_kernel<3, false>), grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax); }
     else hipLaunchKernelGGL(layernorm_fh2_generic_kernel, grid, block, 0, st, x, w, b, y, M, D, eps, scale, absmax);
     A3R_LAUNCH_CHECK();
     return A3R_OK;

@@ -78,6 +78,9 @@ struct a3r_model_s {
     std::vector<float> site_scale[3];
     unsigned* stats = nullptr;       // [MAX_SITES], inside the packed buffer
     int last_phase = -1, last_sites = 0;
+    // LayerNorm -> fh2 sites need no run-time statistics: |y| <= max|gamma| sqrt(D) + max|beta| whatever the input, so their scale is
+    // fixed at finalize from the two weight vectors (gamma pointer -> scale); see ln_static_scale
+    std::map<const float*, float> ln_scale;
     int tap_level = 0;               // a3r_model_set_tap_level: decoder level copied to the taps "level" / "pc0" (parity tests), 0 = none
 };
 
@@ -272,6 +275,26 @@ static int bind_block(a3r_model_s* m, const std::string& p, int D, int hidden, b
     return A3R_OK;
 }
 
+// Scale of a LayerNorm -> fh2 output from its weights alone.  Hard bound: |y| <= g sqrt(D) + b (g = max|gamma|, b = max|beta|; the
+// normalised row has unit variance, so no entry exceeds sqrt(D - 1)).  1 unless that bound could pass 2^15 (then the power of two that
+// keeps it below) or the typical magnitude g + b is under 2^-3 (then raised until g + b reaches [2^-1, 1), never past the bound).
+static float ln_static_scale(float g, float b, int D) {
+    const double bound = (double)g * std::sqrt((double)D) + (double)b, typ = (double)g + (double)b;
+    if (!(bound > 0.0)) return 1.f;
+    int e;
+    std::frexp(bound, &e);                         // bound = f 2^e, f in [0.5, 1)
+    const int kmax = 15 - e;                       // 2^kmax * bound < 2^15
+    int k = 0;
+    if (typ < 0.125) {
+        int et;
+        std::frexp(typ > 0.0 ? typ : bound, &et);
+        k = -et;                                   // 2^k * typ in [0.5, 1)
+    }
+    if (k > kmax) k = kmax;
+    k = k < -40 ? -40 : k > 40 ? 40 : k;
+    return std::ldexp(1.f, k);
+}
+
 extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_bytes, void* stream) {
     A3R_CHECK_ARG(m && packed, "a3r_model_finalize: null argument");
     size_t total = 0;
@@ -378,6 +401,34 @@ extern "C" int a3r_model_finalize(a3r_model_t m, void* packed, size_t packed_byt
         H.h0w = packed_ptr[p + "head.0.weight"]; NEED(p + "head.0.bias", &H.h0b, F / 2);
         H.h2w = packed_ptr[p + "head.2.weight"]; NEED(p + "head.2.bias", &H.h2b, L);
         NEED(p + "head.4.weight", &H.h4w, 4, L, 1, 1); NEED(p + "head.4.bias", &H.h4b, 4);
+    }
+    // --- static scales of the LayerNorm -> fh2 sites (fh2 mode)
+    m->ln_scale.clear();
+    if (m->use_bf3 && m->use_fh2) {
+        std::vector<std::pair<const float*, const float*>> lns;      // (gamma, beta) of every LayerNorm whose output feeds a GEMM
+        auto add_block = [&](const BlockW& b, bool cross) {
+            lns.push_back({b.n1w, b.n1b}); lns.push_back({b.n2w, b.n2b});
+            if (cross) { lns.push_back({b.n3w, b.n3b}); lns.push_back({b.nyw, b.nyb}); }
+        };
+        for (const BlockW& b : m->enc) add_block(b, false);
+        for (const BlockW& b : m->pc) add_block(b, false);
+        for (const BlockW& b : m->dec1) add_block(b, true);
+        for (const BlockW& b : m->dec2) add_block(b, true);
+        float* scratch = reinterpret_cast<float*>(m->stats);          // two words of the (still unused) statistics area
+        for (size_t i = 0; i < lns.size(); i++) {
+            const int Dn = i < 2 * m->enc.size() ? E : D;
+            float gb[2] = {0.f, 0.f};
+            if (int rc = a3r_absmax(lns[i].first, Dn, scratch, stream)) return rc;
+            if (int rc = a3r_absmax(lns[i].second, Dn, scratch + 1, stream)) return rc;
+            A3R_HIP(hipMemcpyAsync(gb, scratch, 8, hipMemcpyDeviceToHost, st));
+            A3R_HIP(hipStreamSynchronize(st));
+            if (!std::isfinite(gb[0]) || !std::isfinite(gb[1])) {
+                set_error("a3r_model_finalize: a LayerNorm weight contains non-finite values");
+                return A3R_EINVAL;
+            }
+            m->ln_scale[lns[i].first] = ln_static_scale(gb[0], gb[1], Dn);
+        }
+        A3R_HIP(hipMemsetAsync(m->stats, 0, 8, st));
     }
     // --- bf3 twins of the nn.Linear weights
     m->w3.clear();
@@ -626,8 +677,11 @@ struct Plan {
         if (skip()) return;
         traced("layernorm", M, D);
         if (fh2()) {
-            const Site s = site(yg);
-            rc = a3r_layernorm_fh2(x, w, b, yg, M, D, 1e-6f, s.scale, s.stat, stream);
+            // static scale (ln_static_scale): no statistics, the kernel keeps its one-row-per-wave grid
+            auto it = m->ln_scale.find(w);
+            const float sc = it == m->ln_scale.end() ? 1.f : it->second;
+            buf_scale[yg] = sc;
+            rc = a3r_layernorm_fh2(x, w, b, yg, M, D, 1e-6f, sc, nullptr, stream);
         } else rc = bf3() ? a3r_layernorm_bf3(x, w, b, yg, M, D, 1e-6f, pair, stream) : a3r_layernorm(x, w, b, yg, M, D, 1e-6f, stream);
     }
     void ln_f32(const float* x, const float* w, const float* b, float* y, int M, int D) {

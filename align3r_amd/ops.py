@@ -66,8 +66,11 @@ def layernorm(x, w, b, eps=1e-6, out=None):
 
 
 def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
-                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False, aux_fh2=None, x_scale=0.0, out_scale=0.0, out_absmax=None):
+                  aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False, aux_fh2=None, x_scale=0.0, out_scale=0.0, out_absmax=None,
+                  head=None):
     e = Epilogue()
+    if head is not None:              # EPI_HEAD: (head_w [4, 128], head_b [4], conf out [M]) -- the caller keeps them alive
+        e.head_w, e.head_b, e.head_conf = head[0].data_ptr(), head[1].data_ptr(), head[2].data_ptr()
     # range control of the fh2 kernels (include/a3r.h): zeros / None = scale 1, no statistics
     e.x_scale, e.out_scale = float(x_scale), float(out_scale)
     e.out_absmax = None if out_absmax is None else out_absmax.data_ptr()
@@ -439,6 +442,8 @@ def conv3x3_fh2(x2: Fh2, wp2: Fh2, shape, bias=None, stride=1, epi=_lib.EPI_NONE
     dev = x2.data.device
     if e.out_fh2:
         out = Fh2(torch.zeros(B * Ho * Wo * Cout * 4, device=dev, dtype=torch.uint8), B * Ho * Wo, Cout, e.out_scale or 1.0)
+    elif epi == _lib.EPI_HEAD:
+        out = torch.empty((B, Ho, Wo, 3), device=dev, dtype=torch.float32)          # pts3d; conf goes to head[2]
     else:
         out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float32)
     check(_lib.load().a3r_conv3x3_fh2(x2.data_ptr(), wp2.data_ptr(), wp2.scale, out.data_ptr(), B, H, W, Cin, Cout, stride, C.byref(e),

@@ -172,3 +172,30 @@ def test_conv3x3_fh2_vs_float64(ops, monkeypatch, tile, B, H, W, Cin, Cout, stri
 def test_upsample2x_fh2(ops):
     x = rnd(2, 7, 9, 64, seed=1)
     assert torch.equal(ops.upsample2x_fh2(x, crop=(13, 18)).data, ops.split_fh2(ops.upsample2x(x, crop=(13, 18))).data)
+
+
+@pytest.mark.parametrize("tile", ["0", "2"])
+@pytest.mark.parametrize("B,H,W", [(1, 16, 24), (2, 19, 13)])
+def test_conv3x3_fh2_head_epilogue(ops, monkeypatch, tile, B, H, W):
+    """A3R_EPI_HEAD: head.2 (3x3 conv 128 -> 128 + ReLU), head.4 (1x1 conv 128 -> 4) and the postprocess fused into one launch
+    (dpt_block.py:323-329, heads/postprocess.py:10-58) against the same steps as separate launches and against float64; a ragged
+    pixel count (19 x 13 x 2 = 494 rows: partial tiles) included."""
+    monkeypatch.setenv("A3R_FH2_TILE", tile)
+    Cin, Cout = 128, 128
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.3)
+    w4, b4 = rnd(4, 128, seed=4, scale=0.1), rnd(4, seed=5, scale=0.1)
+    wp = ops.pack_conv3x3(w)
+    x2, wp2 = ops.split_fh2(x), ops.split_fh2_w(wp.reshape(Cout, 9 * Cin))
+    conf = torch.empty(B, H, W, device="cuda")
+    pts = ops.conv3x3_fh2(x2, wp2, (B, H, W, Cin), b, epi=_lib.EPI_HEAD, head=(w4, b4, conf))
+    t = ops.conv3x3_fh2(x2, wp2, (B, H, W, Cin), b, epi=_lib.EPI_RELU)
+    pts_ref, conf_ref = ops.head_final(t, w4.reshape(4, 128, 1, 1), b4)
+    e = lambda a, c: float((a - c).abs().max() / c.abs().max())
+    assert e(pts, pts_ref) < 2e-6 and e(conf, conf_ref) < 2e-6
+    f = torch.nn.functional.linear(torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1))
+                                   .permute(0, 2, 3, 1), w4.double(), b4.double())
+    d = f[..., :3].norm(dim=-1, keepdim=True)
+    assert e(pts.double(), f[..., :3] / d.clip(min=1e-8) * torch.expm1(d)) < 1e-5
+    assert e(conf.double(), 1 + f[..., 3].exp()) < 1e-5

@@ -220,7 +220,7 @@ def _dev(*arrs):
     return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
 
 
-@pytest.mark.parametrize("case", ["huge_decoder_levels", "tiny_encoder_output"])
+@pytest.mark.parametrize("case", ["huge_decoder_levels", "tiny_encoder_output", "layernorm_gains"])
 def test_tiny_model_outside_the_fp16_range_is_repaired_not_refused(case):
     """Weights rescaled so that (a) the raw decoder tokens that feed the DPT adapters (levels 6 / 9 for depth 12, dpt_head.py:47,
     model.py:229) and the zero-conv inputs are ~1e6 -- far past 65504 --, or (b) the encoder output is ~1e-6: the first forward
@@ -238,17 +238,26 @@ def test_tiny_model_outside_the_fp16_range_is_repaired_not_refused(case):
         # adapters that read the RAW levels 2^-20 x smaller: the function stays well conditioned, the operands leave fp16
         mul(("decoder_embed.weight", "decoder_embed.bias", "patch_embed_point_cloud.proj.weight", "patch_embed_point_cloud.proj.bias"), 2.0 ** 20)
         mul([h + f"act_postprocess.{i}.0.weight" for h in heads for i in (1, 2)], 2.0 ** -20)
-    else:
+    elif case == "tiny_encoder_output":
         # encoder output ~1e-6, its two consumers' weights 2^20 x larger
         mul(("enc_norm.weight", "enc_norm.bias"), 2.0 ** -20)
         mul(["decoder_embed.weight"] + [h + "act_postprocess.0.0.weight" for h in heads], 2.0 ** 20)
+    else:
+        # LayerNorm -> fh2 sites take their scale from the weights alone (|y| <= max|gamma| sqrt(D) + max|beta|, csrc/model.hip
+        # ln_static_scale): one LayerNorm with a gain of 2^14 (its output would pass 65504), one with 2^-16 (its output would sit
+        # in fp16's subnormals), the consumers' weights compensating
+        mul(("enc_blocks.0.norm1.weight", "enc_blocks.0.norm1.bias"), 2.0 ** 14)
+        mul(("enc_blocks.0.attn.qkv.weight",), 2.0 ** -14)
+        mul(("dec_blocks.3.norm3.weight", "dec_blocks.3.norm3.bias"), 2.0 ** -16)
+        mul(("dec_blocks.3.mlp.fc1.weight",), 2.0 ** 16)
     eng = PairEngine(TINY, sd)
     v = make_view_arrays(2, 64, 96)
     args = _dev(v[0][0], v[1][0], v[0][1], v[1][1])
     out = {k: t.cpu().numpy() for k, t in eng.forward(*args).items()}
-    assert eng.range_reruns >= 1
-    scales = eng.site_scales(0)
-    assert (scales != 1.0).any()
+    if case != "layernorm_gains":
+        assert eng.range_reruns >= 1
+        scales = eng.site_scales(0)
+        assert (scales != 1.0).any()
     for k in out:
         assert np.isfinite(out[k]).all(), k
     ref = _forward_np(sd, v)
