@@ -35,10 +35,16 @@ __device__ __forceinline__ uint32_t pk_f16(float a, float b) {       // v_cvt_pk
 __device__ __forceinline__ float f16lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2v, p)[0]; }
 __device__ __forceinline__ float f16hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2v, p)[1]; }
 
-// two (already scaled) floats -> two packed fp16 pairs (low half = a, high half = b)
+// two (already scaled) floats -> two packed fp16 pairs (low half = a, high half = b).  The second plane rn_f16(x - h0) is ONE
+// v_fma_mix per element (f32 x, f16 h0 read straight from the packed pair, f16 result into its half of the destination) instead of
+// convert-back, subtract and convert again: x - h0 is exact in fp32, so both forms round the same number once -- identical bits, half
+// the instructions of the split (the attention kernel splits 16 probabilities per lane and 32-key block beside its MFMAs)
 __device__ __forceinline__ void fh2_split2(float a, float b, uint32_t& p0, uint32_t& p1) {
     p0 = pk_f16(a, b);
-    p1 = pk_f16(a - f16lo(p0), b - f16hi(p0));
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(r) : "v"(a), "v"(b), "v"(p0));
+    p1 = r;
 }
 
 // eight consecutive k (k0 % 8 == 0) of one fh2 row: 32 contiguous bytes

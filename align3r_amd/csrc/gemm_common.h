@@ -5,6 +5,15 @@
 #include "bf3.h"
 #include "fh2.h"
 
+// Between a wave's writes of its private LDS image and its own reads of it (and back): the LDS pipeline executes one wave's DS
+// instructions in program order, so only the COMPILER has to be kept from moving them across each other (wave_barrier); with
+// A3R_EPI_WAIT the wave also drains lgkmcnt first (the form of rounds 1-2).
+#ifdef A3R_EPI_WAIT
+#define A3R_EPI_FENCE() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define A3R_EPI_FENCE() __builtin_amdgcn_wave_barrier()
+#endif
+
 namespace a3r {
 
 struct GroupPtrs {
@@ -293,8 +302,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
                         *reinterpret_cast<uint16_t*>(d + IMG_PITCH + 32) = (uint16_t)(p2 >> 16);
                     }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            A3R_EPI_FENCE();
 #pragma unroll
             for (int it = 0; it < 6; it++) {                          // 32 rows x 12 units = 6 x 64 lanes
                 const int u = it * 64 + lane, r = u / 12, un = u - r * 12;
@@ -303,8 +311,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
                 if ((FULL || (grow < g.M && kcol0 + (un / 3) * 8 < g.N)))
                     *reinterpret_cast<u32x4*>(out3 + bf3_row_offset(grow, g.N, pair3) + bf3_k_offset(kcol0, pair3) + un * 16) = dv;
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                       // the reads are done before the next half overwrites the image
-            __builtin_amdgcn_wave_barrier();
+            A3R_EPI_FENCE();                                          // the reads are ordered before the next half overwrites the image
         }
         return;
     }
@@ -324,8 +331,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
             for (int e = 0; e < 4; e++)
                 lds[(i * 16 + quad * 4 + e) * EPI_LDS_PITCH + j * 16 + lcol] = value(i, j, e, bias, bias_o, do_rope, rope_x, second);
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes are done (the image is wave-private)
-    __builtin_amdgcn_wave_barrier();
+    A3R_EPI_FENCE();                             // this wave's LDS writes are ordered before its reads (the image is wave-private)
     // ---- phase 2: one float4 of one row per lane: residuals, fp32 store, the auxiliary bf3 form
     char* out3 = O3 == 0 ? nullptr : static_cast<char*>(ep.aux_bf3);
     char* out2 = static_cast<char*>(ep.aux_fh2);              // the auxiliary output in fh2 form (fh2 kernels)

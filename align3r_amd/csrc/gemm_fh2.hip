@@ -134,8 +134,7 @@ __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const G
                 *reinterpret_cast<uint32_t*>(d + EPI_FH2_PITCH + 16) = b1;
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        A3R_EPI_FENCE();
 #pragma unroll
         for (int it = 0; it < 4; it++) {                          // 32 rows x 8 units = 4 x 64 lanes
             const int u = it * 64 + lane, r = u >> 3, un = u & 7;
@@ -144,8 +143,7 @@ __device__ __forceinline__ void fh2_epilogue_out_body(const GemmArgs& g, const G
             if (FULL || (grow < g.M && kcol0 + (un >> 1) * 8 < g.N))
                 *reinterpret_cast<fh2_u32x4*>(out + (size_t)grow * pitch + (size_t)(kcol0 >> 3) * 32 + un * 16) = dv;
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // the reads are done before the next half overwrites the image
-        __builtin_amdgcn_wave_barrier();
+        A3R_EPI_FENCE();                                          // the reads are ordered before the next half overwrites the image
     }
 }
 
