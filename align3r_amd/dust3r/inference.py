@@ -28,8 +28,9 @@ def loss_of_one_batch(batch, model, criterion, device, symmetrize_batch=False, u
             view[name] = view[name].to(device, non_blocking=True)
     if symmetrize_batch:
         raise NotImplementedError('symmetrize_batch is a training-time option')
-    if use_amp:
-        raise NotImplementedError('use_amp: the engine computes in fp32')
+    # use_amp (inference.py:44: torch.cuda.amp.autocast(enabled=bool(use_amp))) asks torch for REDUCED precision where it is faster;
+    # the engine has one arithmetic per handle and it is fp32-grade: the flag is accepted and changes nothing (a handle built under
+    # A3R_GEMM=bf16 is the reduced-precision mode of this build)
     pred1, pred2 = model(view1, view2)
     loss = criterion(view1, view2, pred1, pred2) if criterion is not None else None
     result = dict(view1=view1, view2=view2, pred1=pred1, pred2=pred2, loss=loss)
