@@ -44,19 +44,17 @@ def check_if_same_size(pairs):
 
 
 def _check_finite(out):
-    """The default arithmetic (A3R_GEMM=fh2) carries activations as fp16 planes: |activation| must stay below 65504, which holds by
-    a wide margin for LayerNorm-ed transformers but is a property of the checkpoint, not a guarantee.  An overflow surfaces as Inf /
-    NaN in the confidences; fail loudly and name the switch with fp32 range instead of returning garbage.  One reduction over the
-    collected confidences per inference() call (A3R_CHECK_FINITE=0 skips it)."""
+    """Last-resort check that the collected confidences are finite (one reduction per inference() call; A3R_CHECK_FINITE=0 skips it).
+    The range control of the default fh2 arithmetic lives in PairEngine (a3r_model_range_check after every forward: a site that left
+    the fp16-safe band is rescaled and the forward repeated, non-finite inputs raise there) -- an overflow would NOT show here
+    anyway: the NaNs it creates die in the ReLUs of the DPT head (tests/test_gpu_fh2_range.py)."""
     if os.environ.get('A3R_CHECK_FINITE', '1') == '0':
         return out
     for side in ('pred1', 'pred2'):
         conf = out[side].get('conf')
         for c in (conf if isinstance(conf, (list, tuple)) else [conf]):
             if c is not None and not bool(torch.isfinite(c).all()):
-                raise RuntimeError("align3r_amd inference produced non-finite confidences: an activation left the fp16 range of the "
-                                   "default fh2 arithmetic (or the inputs / weights are not finite); rerun with A3R_GEMM=bf3 "
-                                   "(same accuracy, fp32 range)")
+                raise RuntimeError("align3r_amd inference produced non-finite confidences (non-finite inputs or weights?)")
     return out
 
 
