@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
                 ("rope_sin", c_void), ("ps_s", C.c_int), ("ps_h", C.c_int), ("ps_w", C.c_int), ("ps_cout", C.c_int),
                 ("out_bf3", C.c_int), ("aux_bf3", c_void), ("aux_relu", C.c_int), ("x_pair", C.c_int), ("out_pair", C.c_int),
                 ("out_fh2", C.c_int), ("aux_fh2", c_void), ("x_scale", C.c_float), ("out_scale", C.c_float), ("out_absmax", c_void),
-                ("head_w", c_void), ("head_b", c_void), ("head_conf", c_void)]
+                ("head_w", c_void), ("head_b", c_void), ("head_conf", c_void), ("relu_out", C.c_int), ("relu_acc", C.c_int)]
 
 
 class GroupPtrs(C.Structure):
@@ -43,6 +43,16 @@ class ModelConfigC(C.Structure):
                 ("dec_embed_dim", C.c_int), ("dec_depth", C.c_int), ("dec_num_heads", C.c_int),
                 ("mlp_ratio", C.c_int), ("patch_size", C.c_int), ("rope_base", C.c_float),
                 ("feature_dim", C.c_int), ("last_dim", C.c_int), ("layer_dims", C.c_int * 4)]
+
+
+class RaftConfigC(C.Structure):
+    _fields_ = [("initial_dim", C.c_int), ("block_dims", C.c_int * 3), ("n_blocks", C.c_int * 3), ("dim", C.c_int), ("radius", C.c_int),
+                ("corr_levels", C.c_int), ("num_blocks", C.c_int)]
+
+
+class RaftTaps(C.Structure):
+    _fields_ = [("cnet", c_void), ("fmap", c_void), ("corr_pyr", c_void * 4), ("flow_update0", c_void), ("weight0", c_void),
+                ("lookup0", c_void), ("motion0", c_void), ("net", c_void * 4), ("flow8", c_void * 4)]
 
 
 class AlignDesc(C.Structure):
@@ -140,6 +150,13 @@ SIGNATURES = {
     "a3r_model_reset_ranges": (C.c_int, [c_void]),
     "a3r_model_range_stats": (C.c_int, [c_void, c_void, c_void, C.c_int, C.POINTER(C.c_int)]),
     "a3r_model_range_scales": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.POINTER(C.c_int)]),
+    "a3r_raft_create": (C.c_int, [C.POINTER(RaftConfigC), C.POINTER(c_void)]),
+    "a3r_raft_destroy": (C.c_int, [c_void]),
+    "a3r_raft_set_weight": (C.c_int, [c_void, C.c_char_p, c_void, C.c_int, C.POINTER(C.c_int64)]),
+    "a3r_raft_packed_bytes": (C.c_size_t, [c_void]),
+    "a3r_raft_finalize": (C.c_int, [c_void, c_void, C.c_size_t, c_void]),
+    "a3r_raft_workspace_bytes": (C.c_size_t, [c_void, C.c_int, C.c_int, C.c_int]),
+    "a3r_raft_forward": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, C.POINTER(RaftTaps), c_void]),
     "a3r_align_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "a3r_align_create": (C.c_int, [C.POINTER(AlignDesc), C.POINTER(c_void), c_void]),
     "a3r_align_destroy": (C.c_int, [c_void]),

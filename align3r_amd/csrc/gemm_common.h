@@ -158,8 +158,9 @@ __device__ __forceinline__ void gemm_epilogue16_body(const GemmArgs& g, const Gr
                 const bool ok = (FULL || row < g.M) && col_ok;
                 if (epi == A3R_EPI_GELU) v[e] = gelu_erf(v[e]);
                 else if (epi == A3R_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
-                else if (epi == A3R_EPI_RESID) { if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + v[e]; }
-                else if (epi == A3R_EPI_RESID2) { if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v[e]; }
+                else if (epi == A3R_EPI_RESID) { if (ep.relu_acc) v[e] = fmaxf(v[e], 0.f); if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + v[e]; }
+                else if (epi == A3R_EPI_RESID2) { if (ep.relu_acc) v[e] = fmaxf(v[e], 0.f); if (ok) v[e] = P.resid[(size_t)row * g.ldc + col] + P.resid2[(size_t)row * g.ldc + col] + v[e]; }
+                if ((epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) && ep.relu_out) v[e] = fmaxf(v[e], 0.f);
                 if (ok && !only3) {
                     if (epi == A3R_EPI_PIXSHUF) {
                         const int s = ep.ps_s, hw = ep.ps_h * ep.ps_w;
@@ -259,6 +260,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
         }
         if (epi == A3R_EPI_GELU) v = gelu_erf(v);
         else if (epi == A3R_EPI_RELU) v = fmaxf(v, 0.f);
+        else if ((epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) && ep.relu_acc) v = fmaxf(v, 0.f);
         return v;
     };
     if (O3 != 0 && only3) {
@@ -361,7 +363,10 @@ __device__ __forceinline__ void gemm_epilogue16_lds_body(const GemmArgs& g, cons
         const bool ok = col_ok && (FULL || grow < g.M);
         if (!ok) continue;
         const size_t o = (size_t)grow * g.ldc + gcol;
-        if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) v += rs[it];
+        if (epi == A3R_EPI_RESID || epi == A3R_EPI_RESID2) {
+            v += rs[it];
+            if (ep.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
         *reinterpret_cast<f32x4*>(P.C + o) = v;
         if (out3 || out2) {
             if (relu3) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }

@@ -67,8 +67,9 @@ def layernorm(x, w, b, eps=1e-6, out=None):
 
 def make_epilogue(kind=_lib.EPI_NONE, bias=None, resid=None, resid2=None, relu_a=False, rope=None, pixshuf=None, out_bf3=False,
                   aux_bf3=None, aux_relu=False, out_pair=False, out_fh2=False, aux_fh2=None, x_scale=0.0, out_scale=0.0, out_absmax=None,
-                  head=None):
+                  head=None, relu_out=False, relu_acc=False):
     e = Epilogue()
+    e.relu_out, e.relu_acc = int(relu_out), int(relu_acc)
     if head is not None:              # EPI_HEAD: (head_w [4, 128], head_b [4], conf out [M]) -- the caller keeps them alive
         e.head_w, e.head_b, e.head_conf = head[0].data_ptr(), head[1].data_ptr(), head[2].data_ptr()
     # range control of the fh2 kernels (include/a3r.h): zeros / None = scale 1, no statistics

@@ -131,6 +131,13 @@ typedef struct {
     const float* head_w;  /* [4, 128] */
     const float* head_b;  /* [4] */
     float* head_conf;     /* [M] */
+    /* RESID / RESID2 only (fp32 y, LDS-staged or direct epilogue of the 16x16 kernels): y = relu(resid (+ resid2) + acc + bias) -- the
+     * tail of a ResNet BasicBlock, `return self.relu(x + y)` (third_party/RAFT/core/layer.py:141); an aux_bf3 / aux_fh2 twin then holds the
+     * same relu-ed value */
+    int relu_out;
+    /* RESID / RESID2 only: the branch is clamped BEFORE the addition, y = resid + relu(acc + bias) (then relu_out) -- BasicBlock's
+     * `y = relu(bn2(conv2(y))); return relu(x + y)` (layer.py:135-141) */
+    int relu_acc;
 } a3r_epilogue;
 
 /* nn.Linear: y[M, N] = x[M, K] @ w[N, K]^T (+ epilogue).  lda/ldc = row strides in floats
@@ -411,6 +418,47 @@ int a3r_model_range_stats(a3r_model_t m, void* stream, float* stored_absmax, int
 /* (diagnostic) the current scales of plan `phase` (0 = forward, 1 = encode, 2 = decode), in plan order: *n_sites = their number,
  * the first min(capacity, *n_sites) are copied to scales (host). */
 int a3r_model_range_scales(a3r_model_t m, int phase, float* scales, int capacity, int* n_sites);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3b) RAFT2 ("SEA-RAFT") optical flow: the flow provider of cloud_opt_flow (dust3r/cloud_opt_flow/optimizer.py:118-154 ->
+ *      third_party/raft.py:39-73 -> third_party/RAFT/core/raft.py:152-246), csrc/raft.hip.
+ *      Weights: the reference's state_dict names with evaluation-mode BatchNorm folded into the convolution in front of it, the
+ *      ConvNeXt layer scale `gamma` folded into pwconv2, the factor 0.25 of raft.py:216 folded into upsample_weight.2, and
+ *      update_block.encoder.convc1's input channels zero-padded to a multiple of 32 (align3r_amd/raft_weights.py does all four).
+ */
+typedef struct {
+    int initial_dim;       /* 64 */
+    int block_dims[3];     /* 64, 128, 256 */
+    int n_blocks[3];       /* 3, 4, 6 ('resnet34', extractor.py:286) */
+    int dim;               /* 128: hidden = context = dim, feature maps 2 dim */
+    int radius;            /* 4 */
+    int corr_levels;       /* 4 (raft.py:159) */
+    int num_blocks;        /* 2 ConvNeXt refinement blocks */
+} a3r_raft_config;
+typedef struct a3r_raft_s* a3r_raft_t;
+/* optional copies of intermediates for the parity tests (device pointers or NULL), channels-last, h = H / 8, w = W / 8 */
+typedef struct {
+    float* cnet;           /* [B, h, w, 2 dim]  init_conv(cnet(cat(image1, image2)))           raft.py:207-209 */
+    float* fmap;           /* [2 B, h, w, 2 dim] fnet(image1) then fnet(image2)                  raft.py:222-223 */
+    float* corr_pyr[4];    /* [B h w, h_l, w_l]  the correlation pyramid                         corr.py:17-23 */
+    float* flow_update0;   /* [B, h, w, 6]       flow_head(net) before the first iteration       raft.py:213 */
+    float* weight0;        /* [B, h, w, 576]     .25 * upsample_weight(net), same point          raft.py:214 */
+    float* lookup0;        /* [B, h, w, ceil32(levels (2r+1)^2)] the first correlation lookup    raft.py:228 */
+    float* motion0;        /* [B, h, w, dim]     BasicMotionEncoder2's output, first iteration   update.py:108-117 */
+    float* net[4];         /* [B, h, w, dim]     hidden state after iterations 0..3 */
+    float* flow8[4];       /* [B, h, w, 2]       coarse flow after iterations 0..3 */
+} a3r_raft_taps;
+int a3r_raft_create(const a3r_raft_config* cfg, a3r_raft_t* out);
+int a3r_raft_destroy(a3r_raft_t m);
+int a3r_raft_set_weight(a3r_raft_t m, const char* name, const float* ptr, int ndim, const int64_t* shape);
+size_t a3r_raft_packed_bytes(a3r_raft_t m);
+int a3r_raft_finalize(a3r_raft_t m, void* packed, size_t packed_bytes, void* stream);
+size_t a3r_raft_workspace_bytes(a3r_raft_t m, int B, int H, int W);
+/* flow [B, 2, H, W] = RAFT2(image1, image2, iters, test_mode=True)[1]: image* [B, 3, H, W] with values in [0, 255] (the reference
+ * feeds img * 255, optimizer.py:141-146); H, W multiples of 8 (the reference pads to that with InputPadder) and at least
+ * 16 << (corr_levels - 1) (its pyramid needs it, corr.py:22). */
+int a3r_raft_forward(a3r_raft_t m, const float* image1, const float* image2, int B, int H, int W, int iters, float* flow,
+                     void* workspace, size_t workspace_bytes, const a3r_raft_taps* taps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (4) global alignment inner loop: PointCloudOptimizer (cloud_opt/optimizer.py, base_opt.py)

