@@ -5,14 +5,17 @@ temporal smoothing of consecutive camera poses, ego-flow smooth-L1 loss against 
 `flow_loss_start_epoch` / `flow_loss_thre` gating, cosine / linear / cycleN schedules, lr_min default 1e-3
 (cloud_opt_flow/base_opt.py:513).  The loop runs in liba3r (a3r_align_step_epoch).
 
-The optical-flow fields are INPUTS of the path: the reference computes them with RAFT inside the constructor
-(optimizer.py:118-154; SURVEY row N4, not built), here they are passed as ``flow=(flow_ij, flow_ji)``
+The optical-flow fields: the reference computes them with RAFT2 inside the constructor (optimizer.py:118-154); here ``get_flow`` does
+the same with the HIP flow network (align3r_amd/raft.py, csrc/raft.hip) when a network is available --
+``flow_net=`` (a align3r_amd.raft.RAFT2 / a checkpoint path), or the reference's default checkpoint path
+third_party/RAFT/models/Tartan-C-T432x960-M.pth if that file exists -- or they are passed in as ``flow=(flow_ij, flow_ji)``
 ([E,2,H,W] each); the dynamic masks come from ``view['dynamic_mask']`` exactly as in the reference
 (cloud_opt_flow/base_opt.py:129-138).  depth_regularize_weight > 0 adds the scale-invariant log-depth prior towards the
 depth maps captured by _set_init_depthmap (init='mst' captures them, as in the reference).  sam2_mask_refine raises.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from ...aligner import AlignEngine
@@ -24,7 +27,7 @@ class PointCloudOptimizer(_Base):
                  flow_loss_fn='smooth_l1', flow_loss_weight=0.0, depth_regularize_weight=0.0, num_total_iter=300,
                  temporal_smoothing_weight=0, translation_weight=0.1, flow_loss_start_epoch=0.15, flow_loss_thre=50,
                  sintel_ckpt=False, use_self_mask=False, pxl_thre=50, sam2_mask_refine=False, motion_mask_thre=0.35,
-                 flow=None, thr_for_init_conf=False, empty_cache=False, **kwargs):
+                 flow=None, flow_net=None, thr_for_init_conf=False, empty_cache=False, **kwargs):
         if flow_loss_fn != 'smooth_l1':
             raise NotImplementedError("only flow_loss_fn='smooth_l1' (the reference's 'mse' branch is broken: optimizer.py:101)")
         if sam2_mask_refine:
@@ -51,10 +54,10 @@ class PointCloudOptimizer(_Base):
                 masks[j] = torch.as_tensor(view2['dynamic_mask'][v]).bool()
             self.dynamic_masks = masks
         self._flow = None
+        self._flow_pair = None
         if flow_loss_weight > 0:
             if flow is None:
-                raise NotImplementedError('flow_loss_weight > 0 needs precomputed optical flow: pass flow=(flow_ij, flow_ji) '
-                                          '[E,2,H,W]; running RAFT inside the aligner is SURVEY row N4 (not built)')
+                flow = self.get_flow(flow_net)
             if use_self_mask:
                 self.motion_mask_thre = motion_mask_thre
                 self.get_motion_mask_from_pairs(view1, view2, pred1, pred2, torch.as_tensor(flow[0]).float(), torch.as_tensor(flow[1]).float())
@@ -64,6 +67,49 @@ class PointCloudOptimizer(_Base):
             self._flow = dict(flow_ij=torch.as_tensor(fij).float(), flow_ji=torch.as_tensor(fji).float(),
                               dyn=torch.stack(self.dynamic_masks), weight=float(flow_loss_weight), thre=float(flow_loss_thre),
                               start_epoch=float(flow_loss_start_epoch), num_total_iter=int(num_total_iter), pxl_thre=float(pxl_thre))
+
+    def get_flow(self, flow_net=None, device='cuda'):
+        """cloud_opt_flow/optimizer.py:118-154: optical flow of every edge, both directions, from the RAFT2 network in chunks of 12
+        pairs (`flow_net(img_i * 255, img_j * 255, iters=20, test_mode=True)[1]`), and the forward-backward consistency masks
+        (OccMask(th=3.0); the reference computes and keeps them, its loss does not read them).  Returns (flow_ij, flow_ji)."""
+        import os
+        from ...raft import RAFT2, load_RAFT
+        if flow_net is None or isinstance(flow_net, (str, os.PathLike)):
+            path = flow_net or 'third_party/RAFT/models/Tartan-C-T432x960-M.pth'          # optimizer.py:125
+            if not os.path.isfile(path):
+                raise RuntimeError(f'flow_loss_weight > 0 needs optical flow: no RAFT checkpoint at {path!r} -- pass flow_net= (a loaded '
+                                   'align3r_amd.raft.RAFT2 or a checkpoint path) or precomputed flow=(flow_ij, flow_ji) [E,2,H,W]')
+            flow_net = load_RAFT(path)
+        if not isinstance(flow_net, RAFT2):
+            raise TypeError('flow_net must be an align3r_amd.raft.RAFT2 (or a checkpoint path)')
+        if self.imgs is None:
+            raise RuntimeError("get_flow needs the frames: view['img'] is missing")
+        if not self._uniform:
+            raise RuntimeError('the flow term needs images of one shape (np.stack(self.imgs), optimizer.py:122)')
+        flow_net = flow_net.to(device).eval()
+        imgs = np.stack(self.imgs)                                                          # [N, H, W, 3] in [0, 1]
+        ei, ej = [i for i, _ in self.edges], [j for _, j in self.edges]
+        f_ij, f_ji = [], []
+        for s0 in range(0, len(self.edges), 12):                                            # chunk_size = 12 (optimizer.py:135)
+            a = torch.from_numpy(imgs[ei[s0:s0 + 12]]).float().permute(0, 3, 1, 2).contiguous() * 255
+            b = torch.from_numpy(imgs[ej[s0:s0 + 12]]).float().permute(0, 3, 1, 2).contiguous() * 255
+            f_ij.append(flow_net(a, b, iters=20, test_mode=True)[1])
+            f_ji.append(flow_net(b, a, iters=20, test_mode=True)[1])
+        flow_ij, flow_ji = torch.cat(f_ij), torch.cat(f_ji)
+        self._flow_pair = (flow_ij, flow_ji)
+        return flow_ij, flow_ji
+
+    def _valid_mask(self, k):
+        """flow_valid_mask_i / _j (optimizer.py:149-150): forward-backward consistency of the two flow fields.  Nothing on the path
+        reads them (the reference only stores them), so they are evaluated when asked for."""
+        from ..utils.goem_opt import OccMask
+        if self._flow_pair is None:
+            return None
+        a, b = self._flow_pair if k == 0 else self._flow_pair[::-1]
+        return OccMask(th=3.0)(a, b)
+
+    flow_valid_mask_i = property(lambda self: self._valid_mask(0))
+    flow_valid_mask_j = property(lambda self: self._valid_mask(1))
 
     def get_motion_mask_from_pairs(self, view1, view2, pred1, pred2, flow_ij, flow_ji):
         """cloud_opt_flow/optimizer.py:154-235: self-computed dynamic masks.  For every symmetric pair (e, e + E/2) a closed-form

@@ -6,8 +6,7 @@ tests/golden/make_goldens.py --only raft; inputs are rebuilt here by align3r_amd
     correlation-pyramid levels, the first heads, the first correlation lookup and motion features, hidden state and coarse flow after
     every iteration -- at max|a - b| / max|b| < 1e-4, and the final up-sampled flow at 1e-4;
   * RAFT_M (the configuration the reference's load_RAFT builds), called as the reference calls it (iters = 20, test_mode = True):
-    first prediction and final flow.  A recurrent net with random weights amplifies rounding from iteration to iteration, so the
-    20-iteration result is held to a looser bound, stated below, than the per-stage checks.
+    first prediction and final flow, both at 1e-4 (measured: 2-5e-6 after 20 recurrent steps).
 """
 import os
 
@@ -79,8 +78,8 @@ def test_raft_tiny_stages_and_flow(g):
 
 @pytest.mark.parametrize("tag,H,W,seed", [("m1", 128, 160, 11), ("m2", 160, 192, 13)])
 def test_raft_m_as_the_reference_calls_it(g, tag, H, W, seed):
-    """RAFT_M, iters = 20: the first iteration's prediction at 1e-4; the final flow (|flow| up to ~130 px with these random weights,
-    20 recurrent steps) at 2e-3 of its maximum -- measured margins are recorded."""
+    """RAFT_M, iters = 20: the first iteration's prediction and the final flow (|flow| up to ~130 px with these random weights, 20
+    recurrent steps) at 1e-4 of their maximum (measured: 2-5e-6; margins are recorded)."""
     from align3r_amd.raft import RAFT2
     net = RAFT2(RAFT_M, synthetic_raft_state_dict(RAFT_M, 0)).to("cuda").eval()
     i1, i2 = synthetic_raft_frames(1, H, W, seed)
@@ -90,7 +89,7 @@ def test_raft_m_as_the_reference_calls_it(g, tag, H, W, seed):
     e1, e20 = rel_err(one, g[f"{tag}_flow_up_1"]), rel_err(out[1].cpu().numpy(), g[f"{tag}_flow"])
     record_margin(f"raft_m_{tag}_vs_reference", flow_iter1=e1, flow_iter20=e20)
     assert e1 < TOL, e1
-    assert e20 < 2e-3, e20
+    assert e20 < TOL, e20
 
 
 def test_raft_errors_are_loud():
