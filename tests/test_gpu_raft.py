@@ -106,3 +106,40 @@ def test_raft_errors_are_loud():
         RaftEngine(RAFT_TINY, bad)
     with pytest.raises(RuntimeError, match="HIP device"):
         RAFT2(RAFT_TINY, sd)(torch.zeros(1, 3, 128, 160), torch.zeros(1, 3, 128, 160), test_mode=True)
+
+
+def test_cloud_opt_flow_computes_its_flow_with_the_hip_raft():
+    """The reference's flow variant computes optical flow for every edge, both directions, inside its constructor
+    (cloud_opt_flow/optimizer.py:118-154).  Same here when a flow network is given: the fields the aligner receives are exactly
+    RaftEngine's outputs for (img_i * 255, img_j * 255, iters = 20) in chunks of 12, the forward-backward masks exist, and the
+    flow-regularised alignment runs on them."""
+    from align3r_amd.dust3r.cloud_opt_flow import global_aligner
+    from align3r_amd.raft import RAFT2
+    from test_gpu_api import _geom_scene
+    N, H, W = 3, 128, 160
+    edges, p1, p2, c, cams, depths, f = _geom_scene(N, H, W)
+    a, b = synthetic_raft_frames(N, H, W, 21)
+    frames = [torch.from_numpy(a[n] / 255.0 * 2 - 1) for n in range(N)]          # view['img'] is normalised to [-1, 1] (ImgNorm)
+    dyn = [torch.zeros(H, W, dtype=torch.bool) for _ in range(N)]
+    out = dict(view1=dict(idx=[i for i, j in edges], img=torch.stack([frames[i] for i, j in edges]), dynamic_mask=[dyn[i] for i, j in edges]),
+               view2=dict(idx=[j for i, j in edges], img=torch.stack([frames[j] for i, j in edges]), dynamic_mask=[dyn[j] for i, j in edges]),
+               pred1=dict(pts3d=torch.from_numpy(p1), conf=torch.from_numpy(c)),
+               pred2=dict(pts3d_in_other_view=torch.from_numpy(p2), conf=torch.from_numpy(c)))
+    net = RAFT2(RAFT_TINY, synthetic_raft_state_dict(RAFT_TINY, 0))
+    torch.manual_seed(0)
+    scene = global_aligner(out, "cuda", verbose=False, min_conf_thr=1.5, flow_loss_weight=0.01, flow_net=net, num_total_iter=20,
+                           flow_loss_start_epoch=0.0)
+    fij, fji = scene._flow_pair
+    assert tuple(fij.shape) == (len(edges), 2, H, W) and fij.is_cuda
+    imgs = np.stack(scene.imgs)                                                     # [N, H, W, 3] in [0, 1], as rgb() leaves them
+    x = lambda idx: torch.from_numpy(imgs[idx]).float().permute(0, 3, 1, 2).contiguous().cuda() * 255
+    ei, ej = [i for i, j in edges], [j for i, j in edges]
+    want = net._engine.forward(x(ei), x(ej), iters=20)
+    assert torch.equal(fij, want)
+    assert torch.equal(fji, net._engine.forward(x(ej), x(ei), iters=20))
+    vi = scene.flow_valid_mask_i
+    assert tuple(vi.shape)[0] == len(edges) and vi.dtype in (torch.bool, torch.float32)
+    loss = scene.compute_global_alignment(init="mst", niter=20, schedule="linear", lr=0.01)
+    assert np.isfinite(loss)
+    with pytest.raises(RuntimeError, match="no RAFT checkpoint"):
+        global_aligner(out, "cuda", verbose=False, flow_loss_weight=0.01)
