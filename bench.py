@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--no-clip-run", action="store_true", help="skip the extra whole-clip wall clock (inference + init='mst' + 300 iterations)")
     ap.add_argument("--no-bf16-run", action="store_true", help="skip the extra throughput figure of BASELINE config 5's plain-bf16 mode")
     ap.add_argument("--no-align-config3", action="store_true", help="skip the extra aligner figure at BASELINE config 3's size (19 GB)")
+    ap.add_argument("--no-raft-run", action="store_true", help="skip the extra throughput figure of the RAFT2 flow network (BASELINE config 4)")
     return ap.parse_args()
 
 
@@ -377,6 +378,33 @@ def main():
             torch.cuda.empty_cache()
         except Exception as ex:
             res["bf16_mode"] = {"error": f"{type(ex).__name__}: {ex}"}
+
+    # ---- extra (not the headline): the flow provider of BASELINE config 4 -- RAFT2 ("SEA-RAFT", the network cloud_opt_flow runs for every
+    # edge in both directions, optimizer.py:118-154) at the clip's resolution, 12 pairs per call and 20 iterations as the reference
+    # calls it, synthetic weights of the reference's configuration (third_party/RAFT/core/configs/congif_spring_M.json)
+    if not a.no_raft_run and world == 1:
+        try:
+            from align3r_amd.raft import RaftEngine
+            from align3r_amd.raft_weights import RAFT_M, synthetic_raft_state_dict
+            reng = RaftEngine(RAFT_M, synthetic_raft_state_dict(RAFT_M, 0), dev)
+            fa = torch.stack([(frames[i][0] * 0.5 + 0.5) * 255 for i in range(12)]).contiguous()
+            fb = torch.stack([(frames[(i + 1) % a.frames][0] * 0.5 + 0.5) * 255 for i in range(12)]).contiguous()
+            reng.forward(fa, fb, iters=20)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nr = 3
+            for _ in range(nr):
+                reng.forward(fa, fb, iters=20)
+            torch.cuda.synchronize()
+            dtr = (time.perf_counter() - t0) / nr
+            res["raft_flow"] = {"value": round(12 / dtr, 2), "unit": "flow fields/s", "ms_per_call": round(1e3 * dtr, 2), "pairs_per_call": 12,
+                                "iters": 20, "resolution": [H, W],
+                                "note": "RAFT2 forward (both encoders, 4-level correlation pyramid, 20 update iterations, convex up-sampling) on the "
+                                        "three-plane bf16 kernels; config 4 needs 2 fields per edge (1230 edges at 128 frames, swinstride-5)"}
+            del reng, fa, fb
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            res["raft_flow"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # ---- global alignment (config 2: N=16, E=84, P=H*W), random-init state, its own timed region
     if not a.no_align:
