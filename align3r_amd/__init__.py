@@ -11,6 +11,10 @@ _MIRRORED = ["dust3r", "dust3r.model", "dust3r.inference", "dust3r.image_pairs",
 
 
 def install_as_dust3r():
-    """Make ``import dust3r.inference`` etc. resolve to this package's mirror modules."""
+    """Make ``import dust3r.inference`` etc. resolve to this package's mirror modules; ``from third_party.raft import load_RAFT``
+    (dust3r/cloud_opt_flow/optimizer.py:13) to the HIP flow network's loader."""
     for name in _MIRRORED:
         sys.modules[name] = importlib.import_module("align3r_amd." + name)
+    import types
+    tp = sys.modules.setdefault("third_party", types.ModuleType("third_party"))
+    tp.raft = sys.modules["third_party.raft"] = importlib.import_module("align3r_amd.raft")
