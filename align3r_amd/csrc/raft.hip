@@ -33,59 +33,87 @@ struct DirectConvArgs {
     long sb, sc, sy, sx;
     int B, H, W, k, stride, pad, Ho, Wo, Cout;
     float in_mul, in_add;
-    const float* w;      // [Cout][c0 + c1][k][k]
+    const float* w;      // [(c0 + c1) k k][Cout]  (transposed at finalize)
     const float* bias;
     int relu;
     float* y;
 };
+// A thread owns PX = 4 consecutive output columns of one output channel; lanes run over the output channels, so the weight loads
+// (w transposed to [Cin k k][Cout] at finalize) are coalesced and the input loads are wave-wide broadcasts.  (The first version -- one
+// output per thread, weights [Cout][Cin][k][k] -- spent 38 % of the whole flow network in this kernel.)
+constexpr int DC_PX = 4;
 __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
-    const long total = (long)a.B * a.Ho * a.Wo * a.Cout;
-    const int Cin = a.c0 + a.c1, kk = a.k * a.k;
+    const int WoG = (a.Wo + DC_PX - 1) / DC_PX;
+    const long total = (long)a.B * a.Ho * WoG * a.Cout;
+    const int Cin = a.c0 + a.c1;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int co = (int)(i % a.Cout);
         long p = i / a.Cout;
-        const int ox = (int)(p % a.Wo); p /= a.Wo;
+        const int ox0 = (int)(p % WoG) * DC_PX; p /= WoG;
         const int oy = (int)(p % a.Ho);
         const int b = (int)(p / a.Ho);
-        float acc = a.bias ? a.bias[co] : 0.f;
-        const float* wr = a.w + (size_t)co * Cin * kk;
+        float acc[DC_PX];
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int q = 0; q < DC_PX; q++) acc[q] = bias;
         for (int c = 0; c < Cin; c++) {
             const float* src = (c < a.c0 ? a.x0 + (long)c * a.sc : a.x1 + (long)(c - a.c0) * a.sc) + (long)b * a.sb;
             for (int ky = 0; ky < a.k; ky++) {
                 const int iy = oy * a.stride - a.pad + ky;
                 if (iy < 0 || iy >= a.H) continue;
+                const float* row = src + (long)iy * a.sy;
                 for (int kx = 0; kx < a.k; kx++) {
-                    const int ix = ox * a.stride - a.pad + kx;
-                    if (ix < 0 || ix >= a.W) continue;
-                    acc = __fmaf_rn(src[(long)iy * a.sy + (long)ix * a.sx] * a.in_mul + a.in_add, wr[(c * a.k + ky) * a.k + kx], acc);
+                    const float wv = a.w[(size_t)((c * a.k + ky) * a.k + kx) * a.Cout + co];
+#pragma unroll
+                    for (int q = 0; q < DC_PX; q++) {
+                        const int ix = (ox0 + q) * a.stride - a.pad + kx;
+                        if (ix >= 0 && ix < a.W) acc[q] = __fmaf_rn(row[(long)ix * a.sx] * a.in_mul + a.in_add, wv, acc[q]);
+                    }
                 }
             }
         }
-        a.y[i] = a.relu ? fmaxf(acc, 0.f) : acc;
+#pragma unroll
+        for (int q = 0; q < DC_PX; q++)
+            if (ox0 + q < a.Wo) a.y[(((long)b * a.Ho + oy) * a.Wo + ox0 + q) * a.Cout + co] = a.relu ? fmaxf(acc[q], 0.f) : acc[q];
     }
 }
 
-// depthwise 7x7, padding 3, channels-last x [B, h, w, C]; weights wt [49][C] (transposed at finalize), bias [C]
+// depthwise 7x7, padding 3, channels-last x [B, h, w, C]; weights wt [49][C] (transposed at finalize), bias [C].  A thread owns 4
+// consecutive output columns of one channel: 7 x 10 input loads for 4 outputs instead of 4 x 49.
 __global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
                                                       float* __restrict__ y, int B, int h, int w, int C) {
-    const long total = (long)B * h * w * C;
+    const int wG = (w + 3) / 4;
+    const long total = (long)B * h * wG * C;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
         long p = i / C;
-        const int ox = (int)(p % w); p /= w;
+        const int ox0 = (int)(p % wG) * 4; p /= wG;
         const int oy = (int)(p % h);
         const int b = (int)(p / h);
-        float acc = bias[c];
+        float acc[4] = {bias[c], bias[c], bias[c], bias[c]};
         for (int ky = 0; ky < 7; ky++) {
             const int iy = oy - 3 + ky;
             if (iy < 0 || iy >= h) continue;
+            const float* row = x + ((long)b * h + iy) * w * C + c;
+            float v[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++) {
+                const int ix = ox0 - 3 + j;
+                v[j] = (ix >= 0 && ix < w) ? row[(long)ix * C] : 0.f;
+            }
+#pragma unroll
             for (int kx = 0; kx < 7; kx++) {
-                const int ix = ox - 3 + kx;
-                if (ix < 0 || ix >= w) continue;
-                acc = __fmaf_rn(x[(((long)b * h + iy) * w + ix) * C + c], wt[(ky * 7 + kx) * C + c], acc);
+                const float wv = wt[(ky * 7 + kx) * C + c];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int ix = ox0 + q - 3 + kx;
+                    if (ix >= 0 && ix < w) acc[q] = __fmaf_rn(v[q + kx], wv, acc[q]);
+                }
             }
         }
-        y[i] = acc;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (ox0 + q < w) y[(((long)b * h + oy) * w + ox0 + q) * C + c] = acc[q];
     }
 }
 
@@ -210,10 +238,10 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
     }
 }
 
-// [C][49] -> [49][C]
-__global__ void dw_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
+// [N][K] -> [K][N]  (depthwise weights [C][49] -> [49][C]; direct-conv weights [Cout][Cin k k] -> [Cin k k][Cout])
+__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C * 49) wt[(i % 49) * C + i / 49] = w[i];
+    if (i < N * K) wt[(size_t)(i % K) * N + i / K] = w[i];
 }
 
 static inline unsigned grid1d(long n) {
@@ -236,7 +264,7 @@ struct a3r_raft_s {
 
 // ------------------------------------------------------------------------------------------- weight plan
 namespace {
-struct RItem { std::string name; int kind; int N, K; size_t off, tmp; };      // kind 0: conv3x3 [N, K/9 ch]; 1: linear [N, K]; 2: depthwise [C=N]
+struct RItem { std::string name; int kind; int N, K; size_t off, tmp; };      // kind 0: conv3x3 [N, K/9 ch]; 1: linear [N, K]; 2: depthwise [C=N]; 3: direct conv [N, K = Cin 49], transposed
 
 void resnet_convs(const std::string& p, const a3r_raft_config& c, std::vector<RItem>* v, int output_dim, size_t* off) {
     auto add = [&](const std::string& n, int kind, int N, int K) {
@@ -267,10 +295,14 @@ std::vector<RItem> raft_pack_plan(const a3r_raft_config& c, size_t* total) {
     auto add = [&](const std::string& n, int kind, int N, int K) {
         RItem it{n, kind, N, K, off, 0};
         if (kind == 2) { off = align_up(off + (size_t)N * 49 * 4, 256); v.push_back(it); return; }
+        if (kind == 3) { off = align_up(off + (size_t)N * K * 4, 256); v.push_back(it); return; }      // direct-conv weight, transposed
         off = align_up(off + a3r_bf3_w_bytes(N, K), 256);
         if (kind == 0) { it.tmp = off; off = align_up(off + (size_t)N * K * 4, 256); }
         v.push_back(it);
     };
+    add("cnet.conv1.weight", 3, c.initial_dim, 6 * 49);
+    add("fnet.conv1.weight", 3, c.initial_dim, 3 * 49);
+    add("update_block.encoder.convf1.weight", 3, d, 2 * 49);
     resnet_convs("cnet", c, &v, 2 * d, &off);
     resnet_convs("fnet", c, &v, 2 * d, &off);
     add("init_conv.weight", 0, 2 * d, 9 * 2 * d);
@@ -374,10 +406,16 @@ extern "C" int a3r_raft_finalize(a3r_raft_t m, void* packed, size_t packed_bytes
             A3R_CHECK_ARG(ok, "a3r_raft_finalize: weight '%s' must be [%d, %d] (or [%d, %d, 1, 1])", it.name.c_str(), it.N, it.K, it.N, it.K);
             if (int rc = a3r_split_bf3_w(wi->second.p, it.K, pk + it.off, it.N, it.K, stream)) return rc;
             m->twin[it.name] = pk + it.off;
+        } else if (it.kind == 3) {
+            if (int rc = rneed(m, it.name, {it.N, it.K / 49, 7, 7}, &src)) return rc;
+            float* wt = reinterpret_cast<float*>(pk + it.off);
+            hipLaunchKernelGGL(transpose_kernel, dim3((it.N * it.K + 255) / 256), dim3(256), 0, as_stream(stream), src, wt, it.N, it.K);
+            A3R_LAUNCH_CHECK();
+            m->aux[it.name] = wt;
         } else {
             if (int rc = rneed(m, it.name, {it.N, 1, 7, 7}, &src)) return rc;
             float* wt = reinterpret_cast<float*>(pk + it.off);
-            hipLaunchKernelGGL(dw_transpose_kernel, dim3((it.N * 49 + 255) / 256), dim3(256), 0, as_stream(stream), src, wt, it.N);
+            hipLaunchKernelGGL(transpose_kernel, dim3((it.N * 49 + 255) / 256), dim3(256), 0, as_stream(stream), src, wt, it.N, 49);
             A3R_LAUNCH_CHECK();
             m->aux[it.name] = wt;
         }
@@ -409,6 +447,11 @@ struct RPlan {
         auto it = m->w.find(n);
         if (it == m->w.end()) { if (!rc) { set_error("a3r_raft_forward: missing weight '%s'", n.c_str()); rc = A3R_ESTATE; } return nullptr; }
         return it->second.p;
+    }
+    const float* auxw(const std::string& n) {
+        auto it = m->aux.find(n);
+        if (it == m->aux.end()) { if (!rc) { set_error("a3r_raft_forward: weight '%s' was not packed", n.c_str()); rc = A3R_ESTATE; } return nullptr; }
+        return it->second;
     }
     const void* twin(const std::string& n) {
         auto it = m->twin.find(n);
@@ -538,8 +581,8 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         float* s = ar.alloc((size_t)B * H2 * W2 * c.initial_dim);
         P.launch([&](hipStream_t st) {
             DirectConvArgs a = {img1, img2, 3, 3, 3L * H * W, (long)H * W, W, 1, B, H, W, 7, 2, 3, H2, W2, c.initial_dim, 2.f / 255.f, -1.f,
-                                P.wptr("cnet.conv1.weight"), P.wptr("cnet.conv1.bias"), 1, s};
-            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * W2 * c.initial_dim)), dim3(256), 0, st, a);
+                                P.auxw("cnet.conv1.weight"), P.wptr("cnet.conv1.bias"), 1, s};
+            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * ((W2 + DC_PX - 1) / DC_PX) * c.initial_dim)), dim3(256), 0, st, a);
         });
         float* c3 = ar.alloc3(Bhw, 2 * d);
         resnet(P, "cnet", s, B, H2, W2, nullptr, c3, 2 * d);
@@ -556,8 +599,8 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         for (int k = 0; k < 2; k++)
             P.launch([&](hipStream_t st) {
                 DirectConvArgs a = {k ? img2 : img1, nullptr, 3, 0, 3L * H * W, (long)H * W, W, 1, B, H, W, 7, 2, 3, H2, W2, c.initial_dim, 2.f / 255.f, -1.f,
-                                    P.wptr("fnet.conv1.weight"), P.wptr("fnet.conv1.bias"), 1, s + (size_t)k * B * H2 * W2 * c.initial_dim};
-                hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * W2 * c.initial_dim)), dim3(256), 0, st, a);
+                                    P.auxw("fnet.conv1.weight"), P.wptr("fnet.conv1.bias"), 1, s + (size_t)k * B * H2 * W2 * c.initial_dim};
+                hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * ((W2 + DC_PX - 1) / DC_PX) * c.initial_dim)), dim3(256), 0, st, a);
             });
         resnet(P, "fnet", s, 2 * B, H2, W2, fm, nullptr, 2 * d);
     }
@@ -644,8 +687,8 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         P.pack_cols(cf, 2 * d, 0, tmp, d + d / 2, d + d / 2, Bhw);
         P.launch([&](hipStream_t st) {                                                                      // flo = relu(convf1(flow)): 7x7 on 2 channels
             DirectConvArgs a = {flow8, nullptr, 2, 0, hw * 2, 1, (long)w * 2, 2, B, h, w, 7, 1, 3, h, w, d, 1.f, 0.f,
-                                P.wptr(enc + "convf1.weight"), P.wptr(enc + "convf1.bias"), 1, f1};
-            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d(Bhw * d)), dim3(256), 0, st, a);
+                                P.auxw(enc + "convf1.weight"), P.wptr(enc + "convf1.bias"), 1, f1};
+            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * h * ((w + DC_PX - 1) / DC_PX) * d)), dim3(256), 0, st, a);
         });
         P.split(f1, d, f13, Bhw, d);
         P.conv3(f13, enc + "convf2", tmp, B, h, w, d, d / 2, 1, P.epi(A3R_EPI_RELU, nullptr));              // flo = relu(convf2(flo))
@@ -664,7 +707,7 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
             P.pack_cols(X, 3 * d, 0, net, d, d, Bhw);
             P.launch([&](hipStream_t st) {
                 auto wi = P.m->aux.find(q + "dwconv.weight");
-                hipLaunchKernelGGL(dwconv7_kernel, dim3(grid1d(Bhw * 3 * d)), dim3(256), 0, st, X, wi->second, P.wptr(q + "dwconv.bias"), dw, B, h, w, 3 * d);
+                hipLaunchKernelGGL(dwconv7_kernel, dim3(grid1d((long)B * h * ((w + 3) / 4) * 3 * d)), dim3(256), 0, st, X, wi->second, P.wptr(q + "dwconv.bias"), dw, B, h, w, 3 * d);
             });
             if (!P.skip()) P.rc = a3r_layernorm_bf3(dw, P.wptr(q + "norm.weight"), P.wptr(q + "norm.bias"), ln3, (int)Bhw, 3 * d, 1e-6f, 0, stream);
             a3r_epilogue eg = P.epi(A3R_EPI_GELU, nullptr);
