@@ -649,7 +649,9 @@ extern "C" int a3r_upsample2x_fh2(const float* x, void* y2, int B, int H, int W,
     const long total = (long)B * Hc * Wc * (C / 4);
     ProfScope prof(PK_ELEMENTWISE, 16.0 * total + 4.0 * B * H * W * C, as_stream(stream));
     dim3 grid = upsample_grid(B, Hc, Wc, C / 8);
-    const unsigned ycap = 8192 / grid.x > 1 ? 8192 / grid.x : 1;      // ~8 k workgroups: each loops over rows and publishes one statistics atomic
+    // every workgroup loops over ~8 rows and publishes ONE statistics atomic (a long per-thread loop of dependent row loads is
+    // latency-bound: 63 rows per workgroup cost +15 % on the full-resolution map; one row per workgroup is half a million atomics)
+    const unsigned ycap = (grid.y + 7) / 8;
     if (grid.y > ycap) grid.y = ycap;
     hipLaunchKernelGGL(upsample2x_kernel<2>, grid, dim3(256), 0, as_stream(stream), x, static_cast<float*>(y2), B, H, W,
                        C / 4, Hc, Wc, scale, absmax);
