@@ -14,6 +14,8 @@
 #include "common.h"
 #include "fh2.h"
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 namespace a3r {
 
@@ -234,6 +236,229 @@ __global__ __launch_bounds__(A4T, 2) void attn_fh2_kernel(Attn4Args a) {
     fh2_publish_block(a.out_absmax, amax, s_amax);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second form (round 3, default): V arrives like K -- by LDS-DMA into a row-major [key][256 B] image -- and its transposed MFMA
+// operand is read with gfx950's ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group, delivered column-major): no register
+// staging of V (16 VGPRs live across the whole tile in the first form), no 2-byte transposition stores (32 per thread and tile).
+// The registers that frees pay for a one-deep prefetch of the K and V fragments: the first form's read -> wait -> multiply order
+// exposed the LDS latency eight times per 32-key block of each product, and prefetching there cost the third workgroup per CU.
+// LDS image of a 64-key tile (K and V alike): row = key, 256 bytes = 16 chunks of 16 bytes in the LOGICAL order [plane 0: channel
+// groups 0..7 | plane 1: channel groups 0..7] (the DMA's source address de-interleaves the fh2 row), stored at physical chunk
+// c ^ swz(row), swz(row) = ((row & 3) << 2) | ((row >> 2) & 3): conflict-free for the row reads of the 32x32x16 A operand (S^T = K Q^T)
+// and for the transposed reads (cdna_hip_programming.md T10, image (b)).  K double-buffered, V single-buffered (its DMA for tile t + 1
+// is issued when every wave has finished tile t and has the first block's QK^T and softmax to land): 48 KB, three workgroups per CU.
+#ifndef A3R_ATTN_SB
+#define A3R_ATTN_SB 1
+#endif
+#if A3R_ATTN_SB == 1
+#define B4_PIN() __builtin_amdgcn_sched_barrier(0)
+#elif A3R_ATTN_SB == 2
+#define B4_PIN() __builtin_amdgcn_sched_barrier(0x6)        // VALU and SALU may cross, MFMA and DS may not
+#else
+#define B4_PIN()
+#endif
+constexpr int B4_ROW = 256;
+constexpr int B4_TILE = A4K * B4_ROW;          // 16 KB
+constexpr int B4_LDS_BYTES = 3 * B4_TILE;      // K[2] + V
+typedef short b4_s16x4 __attribute__((ext_vector_type(4)));
+typedef short b4_s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int b4_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ b4_s16x4 b4_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) b4_s16x4*)(p));
+}
+
+__global__ __launch_bounds__(A4T, 3) void attn_fh2_v2_kernel(Attn4Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                // [2][64 keys][256 B]
+    char* Vs = smem + 2 * B4_TILE;                  // [64 keys][256 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, half = lane >> 5;
+    const int nqb = (a.Nq + A4Q - 1) / A4Q;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int group = (seq / nqb) * 8 + xcd, qb = seq - (seq / nqb) * nqb;
+    if (group >= a.B * a.H) return;                 // uniform per workgroup
+    const int h = group % a.H, b = group / a.H;
+    const int q_row = qb * A4Q + wave * 32 + qi;
+    const int q_ld = q_row < a.Nq ? q_row : a.Nq - 1;
+
+    f16x8 qf[4][2];
+    {
+        const char* qp = a.q + ((size_t)b * a.Nq + q_ld) * a.pq + h * 256;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) qf[s][p] = *reinterpret_cast<const f16x8*>(qp + ((2 * s + half) * 2 + p) * 16);
+    }
+    // ---- DMA: slot u = tid + 256 i -> (row = (tid >> 4) + 16 i, physical chunk tid & 15); swz(row) does not depend on i
+    const int drow = tid >> 4;
+    const int dch = (tid & 15) ^ b4_swz(drow);                         // logical chunk this thread fetches
+    const int dsrc = ((dch & 7) * 2 + (dch >> 3)) * 16;                // its byte offset in the fh2 row slice of the head
+    const char* kbase = a.k + (size_t)b * a.Nk * a.pk + h * 256 + dsrc;
+    const char* vbase = a.v + (size_t)b * a.Nk * a.pv + h * 256 + dsrc;
+    auto issue = [&](const char* base, size_t pitch, int k0, char* buf) {
+        char* dst = buf + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int kk = min(k0 + drow + 16 * i, a.Nk - 1);          // keys past Nk: finite copies (masked to -inf / multiplied by p = 0)
+            __builtin_amdgcn_global_load_lds((a4_gptr)(base + (size_t)kk * pitch), (a4_lptr)(dst + 4096 * i), 16, 0, 0);
+        }
+    };
+    // ---- fragment addresses (bytes inside a tile)
+    const int ksw = b4_swz(qi);
+    int koff[4][2];                                                    // K row read: row qi (+ 32 kb), logical chunk p 8 + 2 st + half
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) koff[st][p] = qi * B4_ROW + ((((p << 3) | (st << 1) | half) ^ ksw) << 4);
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, dsub = (lane >> 4) & 1;
+    int voff[2][2][2];                                                 // V transposed read [plane][d block][key group of 4]
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; g2++) {
+                const int row = 4 * half + 8 * g2 + tq;                // (+ 16 s2 + 32 kb: immediates)
+                const int ch = (p << 3) + 4 * db + 2 * dsub + (tp >> 1);
+                const int sw = (tq << 2) | ((half + 2 * g2) & 3);      // = swz(row + 16 s2 + 32 kb)
+                voff[p][db][g2] = row * B4_ROW + ((ch ^ sw) << 4) + 8 * (tp & 1);
+            }
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) oacc[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float SCALE_LOG2E = a.scale_log2e;
+    const int ntiles = (a.Nk + A4K - 1) / A4K;
+    issue(kbase, a.pk, 0, Ks);
+    issue(vbase, a.pv, 0, Vs);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // Q and K tile 0 have landed (V tile 0 may be in flight)
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int k0 = t * A4K;
+        const bool more = t + 1 < ntiles;                              // uniform
+        if (more) issue(kbase, a.pk, k0 + A4K, Ks + ((t + 1) & 1) * B4_TILE);      // that buffer was last read in tile t - 1
+        const char* Kt = Ks + (t & 1) * B4_TILE;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            // ---- S^T = K Q^T, fragments of d-step st + 1 requested before the MFMAs of d-step st
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[e] = 0.f;
+            f16x8 kf[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) kf[0][p] = *reinterpret_cast<const f16x8*>(Kt + kb * 32 * B4_ROW + koff[0][p]);
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                if (st < 3) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) kf[(st + 1) & 1][p] = *reinterpret_cast<const f16x8*>(Kt + kb * 32 * B4_ROW + koff[st + 1][p]);
+                }
+                B4_PIN();
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][1], qf[st][0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][0], qf[st][1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][0], qf[st][0], s, 0, 0, 0);
+                B4_PIN();
+            }
+            // ---- online softmax, exactly as the first form
+            if (k0 + kb * 32 + 32 > a.Nk) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (key >= a.Nk) s[e] = -INFINITY;
+                }
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; e++) mx = fmaxf(mx, s[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
+            m_run = m_new;
+            const float off = __fmaf_rn(-m_new, SCALE_LOG2E, A4_PSHIFT);
+            float lsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float p = __builtin_amdgcn_exp2f(__fmaf_rn(s[e], SCALE_LOG2E, off));
+                s[e] = p;
+                lsum += p;
+            }
+            l_run = l_run * alpha + lsum;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) oacc[i][e] *= alpha;
+            }
+            if (kb == 0) {
+                // V tile t: this wave's DMAs (issued at the end of tile t - 1, i.e. BEFORE K tile t + 1's) have landed, then everybody's
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // ---- O^T += V^T P^T; the transposed V fragments of the next (s2, db) are requested before the current MFMAs
+            a4_u32x4 pf[2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int mm = 0; mm < 4; mm++) {
+                    uint32_t p0, p1;
+                    fh2_split2(s[8 * s2 + 2 * mm], s[8 * s2 + 2 * mm + 1], p0, p1);
+                    pf[s2][0][mm] = p0; pf[s2][1][mm] = p1;
+                }
+            auto vread = [&](int step, b4_s16x8 (&vf)[2]) {             // step = 2 s2 + db
+                const int s2 = step >> 1, db = step & 1;
+                const char* base = Vs + (kb * 32 + s2 * 16) * B4_ROW;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const b4_s16x4 lo = b4_tr_read(base + voff[p][db][0]), hi = b4_tr_read(base + voff[p][db][1]);
+                    vf[p] = b4_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            };
+            b4_s16x8 vf[2][2];
+            vread(0, vf[0]);
+#pragma unroll
+            for (int step = 0; step < 4; step++) {
+                if (step < 3) vread(step + 1, vf[(step + 1) & 1]);
+                B4_PIN();
+                const int s2 = step >> 1, db = step & 1;
+                const f16x8 b0 = __builtin_bit_cast(f16x8, pf[s2][0]), b1 = __builtin_bit_cast(f16x8, pf[s2][1]);
+                const f16x8 v0 = __builtin_bit_cast(f16x8, vf[step & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[step & 1][1]);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0, oacc[db], 0, 0, 0);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b1, oacc[db], 0, 0, 0);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b0, oacc[db], 0, 0, 0);
+                B4_PIN();
+            }
+        }
+        // every wave is done with V tile t and K tile t; K tile t + 1 (issued at the top of this iteration) has landed for everybody
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) issue(vbase, a.pv, k0 + A4K, Vs);
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = a.out_mul / l_tot;
+    float amax = 0.f;
+    if (q_row < a.Nq) {
+        char* op = a.o + ((size_t)b * a.Nq + q_row) * a.po;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = {oacc[db][4 * g] * inv_l, oacc[db][4 * g + 1] * inv_l, oacc[db][4 * g + 2] * inv_l,
+                                 oacc[db][4 * g + 3] * inv_l};
+                amax = fh2_amax4(amax, v);
+                fh2_store4(op, h * 64 + db * 32 + 8 * g + 4 * half, v);
+            }
+    }
+    __shared__ unsigned s_amax[A4T / 64];
+    fh2_publish_block(a.out_absmax, amax, s_amax);
+}
+
 }  // namespace a3r
 using namespace a3r;
 
@@ -251,15 +476,21 @@ extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ld
     A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_fh2: row strides must be multiples of 8");
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q2) | reinterpret_cast<uintptr_t>(k2) | reinterpret_cast<uintptr_t>(v2) |
                     reinterpret_cast<uintptr_t>(o2)) & 15) == 0, "a3r_attention_fh2: pointers must be 16-byte aligned");
+    static const bool v1 = getenv("A3R_ATTN") && std::string(getenv("A3R_ATTN")) == "v1";      // A/B switch: the register-staged V form
     static PerDeviceOnce attr_once;
-    A3R_HIP(attr_once.ensure([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES); }));
+    A3R_HIP(attr_once.ensure([&] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_BYTES);
+        return e;
+    }));
     Attn4Args a = {static_cast<const char*>(q2), static_cast<const char*>(k2), static_cast<const char*>(v2), static_cast<char*>(o2),
                    (size_t)ldq * 4, (size_t)ldk * 4, (size_t)ldv * 4, (size_t)ldo * 4, B, H, Nq, Nk,
                    0.125f * 1.4426950408889634f / (r.q_scale * r.k_scale), r.out_scale / r.v_scale, r.out_absmax};
     const int nqb = (Nq + A4Q - 1) / A4Q, groups = B * H;
     dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION_FH2, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
-    hipLaunchKernelGGL(attn_fh2_kernel, grid, dim3(A4T), A4_LDS_BYTES, as_stream(stream), a);
+    if (v1) hipLaunchKernelGGL(attn_fh2_kernel, grid, dim3(A4T), A4_LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL(attn_fh2_v2_kernel, grid, dim3(A4T), B4_LDS_BYTES, as_stream(stream), a);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }

@@ -6,7 +6,7 @@
 // zero-convs); the DPT convolutions and the attention products stay on the bf3 kernels.
 //
 // Structure (64-wide waves), as gemm_bf3.hip: a workgroup computes a BM x BN tile with WM x WN waves of 16x16 accumulator tiles;
-// K is walked in 32-deep stages copied global -> LDS by LDS-DMA (global_load_lds_dwordx4), NS stages deep, one raw s_barrier per
+// K is walked in 32-deep stages copied global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), NS stages deep, one raw s_barrier per
 // stage with a counted s_waitcnt vmcnt.  A stage's LDS image is [rows][8 units] (128 bytes = one cache line per row); ds_read_b128
 // conflicts are removed by an XOR swizzle of the unit index applied on the DMA's SOURCE side (the LDS image is lane-linear):
 // physical unit j of row r holds logical unit j ^ swz(r), swz(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 2), conflict-free for the
@@ -20,7 +20,6 @@
 
 namespace a3r {
 
-typedef const __attribute__((address_space(1))) void* fh2_gptr;
 typedef __attribute__((address_space(3))) void* fh2_lptr;
 
 template <int N> __device__ __forceinline__ void fh2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -40,10 +39,15 @@ struct Fh2Args {
     int gm;                   // row tiles per L2 block: workgroup ids walk gm row tiles before the next column tile (1 = row-major tile order)
 };
 
-// all-zero source for the padding taps of the implicit conv (LDS-DMA has no predicated zero fill)
-__device__ __attribute__((aligned(16))) unsigned int g_fh2_zero[4];
-
 __device__ __forceinline__ int fh2_swz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }
+// One LDS-DMA piece through a raw buffer resource (base, 1 GB window): lane address = base + voff + soff, 16 bytes to dst + lane * 16;
+// a lane with voff >= 2^30 fetches nothing and gets zeros (tools/buf_oob_lab.hip).  A plain function on purpose: called with
+// template-dependent arguments from inside the kernel template, the builtin makes the HOST pass drop the kernel's stub silently.
+constexpr unsigned FH2_DMA_WINDOW = 0x40000000u, FH2_DMA_OOB = 0x80000000u;
+__device__ __forceinline__ void fh2_dma16(const char* base, fh2_lptr dst, unsigned voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, FH2_DMA_WINDOW, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
+}
 
 // ---- out_fh2 epilogue: bias / GELU / ReLU in the accumulator layout, the two fp16 planes go to a wave-private LDS image shaped like
 // the final memory (32 rows x 128 bytes per 32-column block), and come back one 16-byte unit per lane: every store instruction
@@ -249,22 +253,36 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     // AMODE 0: A is an fh2 matrix [M, K].  AMODE 1: implicit 3x3 conv (padding 1, stride 1 or 2) over an fh2 channels-last map
     // x [B, H, W, Cin]: row m of A is output pixel m, its K axis is (tap, ci) -- stage kt covers 32 channels of ONE tap, i.e. one
     // 128-byte line of one input pixel, or zeros where the tap falls into the padding.
-    const char* srcA[LA];       // AMODE 0: row pointer at k = 0; AMODE 1: the centre tap's pixel, channel 0
+    // DMA sources as raw buffer resources (buffer_load_dwordx4 ... lds): a per-lane 32-bit byte offset relative to the tile's first row
+    // and the k offset in an SGPR -- no vector address arithmetic per piece (the flat form added two 64-bit VALU operations to every
+    // DMA and kept a pointer pair per piece alive).  AMODE 1: the base is moved by the tap's (uniform, possibly negative) displacement
+    // and the lanes whose tap falls into the padding carry an out-of-range offset, for which the hardware writes zeros to LDS
+    // (tools/buf_oob_lab.hip) and fetches nothing.
+    unsigned voffA[LA], voffB[LB];
     int tapsA[LA];              // AMODE 1: bit t set <=> tap t = 3 dy + dx lies inside the map
-    const char* srcB[LB];
+    const char* baseA;
+    if (AMODE == 0) {
+        baseA = reinterpret_cast<const char*>(P.A) + (size_t)m0 * pitch;
+    } else {
+        const int hw = g.cHo * g.cWo;
+        const int b = m0 / hw, rem = m0 - b * hw;
+        const int oy = rem / g.cWo, ox = rem - oy * g.cWo;
+        baseA = reinterpret_cast<const char*>(P.A) + (((size_t)b * g.cH + oy * g.cStride) * g.cW + ox * g.cStride) * ((size_t)g.cCin * 4);
+    }
 #pragma unroll
     for (int i = 0; i < LA; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
         const int gm = FULL ? m0 + r : min(m0 + r, g.M - 1);       // rows past M are computed on a copy of the last row, never stored
         if (AMODE == 0) {
-            srcA[i] = reinterpret_cast<const char*>(P.A) + (size_t)gm * pitch + (j ^ fh2_swz(r)) * 16;
+            voffA[i] = (unsigned)(gm - m0) * (unsigned)pitch + (j ^ fh2_swz(r)) * 16;
             tapsA[i] = 0;
         } else {
             const int hw = g.cHo * g.cWo;
             const int b = gm / hw, rem = gm - b * hw;
             const int oy = rem / g.cWo, ox = rem - oy * g.cWo;
             const int iy = oy * g.cStride, ix = ox * g.cStride;     // centre tap
-            srcA[i] = reinterpret_cast<const char*>(P.A) + (((size_t)b * g.cH + iy) * g.cW + ix) * ((size_t)g.cCin * 4) + (j ^ fh2_swz(r)) * 16;
+            const char* centre = reinterpret_cast<const char*>(P.A) + (((size_t)b * g.cH + iy) * g.cW + ix) * ((size_t)g.cCin * 4);
+            voffA[i] = (unsigned)(centre - baseA) + (j ^ fh2_swz(r)) * 16;      // pixels of one tile: monotonic in m, far below 2^30
             int mask = 0;
 #pragma unroll
             for (int t = 0; t < 9; t++) {
@@ -278,29 +296,27 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     for (int i = 0; i < LB; i++) {
         const int slot = tid + NT * i, r = slot >> 3, j = slot & 7;
         const int gn = FULL ? n0 + r : min(n0 + r, g.N - 1);
-        srcB[i] = reinterpret_cast<const char*>(P.Wt) + (size_t)gn * pitch + (j ^ fh2_swz(r)) * 16;
+        voffB[i] = (unsigned)(gn - n0) * (unsigned)pitch + (j ^ fh2_swz(r)) * 16;
     }
+    const char* baseB = reinterpret_cast<const char*>(P.Wt) + (size_t)n0 * pitch;
     int c_tap = 0, c_ci = 0;                                          // AMODE 1: (tap, first channel) of the next stage to issue (stages are issued in order)
     auto issue = [&](int kt, int buf) {
         char* base = smem + buf * STAGE + wave * 1024;               // wave-uniform: the DMA adds lane * 16
-        const size_t koff = (size_t)kt * 128;
-        long delta = 0;
-        if (AMODE == 1) {
-            const int dy = c_tap / 3, dx = c_tap - 3 * dy;
-            delta = ((long)(dy - 1) * g.cW + (dx - 1)) * ((long)g.cCin * 4) + (long)c_ci * 4;
-        }
+        const int koff = kt * 128;
+        if (AMODE == 0) {
 #pragma unroll
-        for (int i = 0; i < LA; i++) {
-            const char* src = AMODE == 0 ? srcA[i] + koff : ((tapsA[i] >> c_tap) & 1 ? srcA[i] + delta : reinterpret_cast<const char*>(g_fh2_zero));
-            __builtin_amdgcn_global_load_lds((fh2_gptr)src, (fh2_lptr)(base + NT * 16 * i), 16, 0, 0);
-        }
-        if (AMODE == 1) {
+            for (int i = 0; i < LA; i++) fh2_dma16(baseA, (fh2_lptr)(base + NT * 16 * i), voffA[i], koff);
+        } else {
+            const int dy = c_tap / 3, dx = c_tap - 3 * dy;
+            const long delta = ((long)(dy - 1) * g.cW + (dx - 1)) * ((long)g.cCin * 4) + (long)c_ci * 4;
+#pragma unroll
+            for (int i = 0; i < LA; i++)
+                fh2_dma16(baseA + delta, (fh2_lptr)(base + NT * 16 * i), ((tapsA[i] >> c_tap) & 1) ? voffA[i] : FH2_DMA_OOB, 0);
             c_ci += 32;
             if (c_ci >= g.cCin) { c_ci = 0; c_tap++; }
         }
 #pragma unroll
-        for (int i = 0; i < LB; i++)
-            __builtin_amdgcn_global_load_lds((fh2_gptr)(srcB[i] + koff), (fh2_lptr)(base + SA * 16 + NT * 16 * i), 16, 0, 0);
+        for (int i = 0; i < LB; i++) fh2_dma16(baseB, (fh2_lptr)(base + SA * 16 + NT * 16 * i), voffB[i], koff);
     };
     const int nk = g.K / 32;
     constexpr int TM = WTM / 16, TN = WTN / 16;
