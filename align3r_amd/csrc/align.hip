@@ -247,6 +247,14 @@ __device__ __forceinline__ bool arrive_last(int* counter, int expected, int* fla
     return *flag != 0;
 }
 
+// Lab build only (-DA3R_ALIGN_STAMPS, never the shipped library): s_memtime stamps of the phases of every workgroup of the main
+// kernel, kept in SGPRs and stored once at the end (tools/align_stamps.py)
+#ifdef A3R_ALIGN_STAMPS
+__device__ unsigned long long g_align_stamps[8192 * 8];
+#define A3R_STAMP(i) (stamp[i] = __builtin_amdgcn_s_memtime())
+#else
+#define A3R_STAMP(i)
+#endif
 // >= 4 waves per SIMD: the streaming loop needs <= 128 VGPRs; the (cold) tail may not raise the allocation
 #ifndef A3R_ALIGN_MIN_WAVES
 #define A3R_ALIGN_MIN_WAVES 4
@@ -260,10 +268,25 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
     const int* __restrict__ inc_ptr, const int* __restrict__ inc, const float* __restrict__ edge_xf,
     const float* __restrict__ img_xf, const int* __restrict__ imw, const int* __restrict__ imarea, const int* __restrict__ order) {
     __shared__ float red[2][EB][16][16];
+#ifdef A3R_ALIGN_STAMPS
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    A3R_STAMP(0);
     // images are dispatched longest first (order[] sorts them by their number of incident edge sides): the last round of
-    // workgroups is then made of the short ones
-    const int n = order[blockIdx.y], chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroups is then made of the short ones.  A dispatch slot's row of the table is {image, first and last incidence slot, the
+    // first two (edge, side) codes}: ONE scalar load after which the first two edge sides are requested, before anything else --
+    // the prologue used to be a chain of five dependent memory round trips (order -> inc_ptr -> inc -> LDS -> edge data) during
+    // which the workgroup streamed nothing (15 % of its lifetime by s_memtime stamps, tools/align_stamps.py)
+    const int* tb = order + blockIdx.y * 8;
+    const int n = tb[0], kbeg = tb[1], kend = tb[2];
+    const int chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = d.P;
+    constexpr int PSTEP = VEC ? 1 : TPB;
+    const int pix0 = chunk * CHUNK + (VEC ? tid * PXT : tid);       // pixel i of this thread: pix0 + i * PSTEP
+    bool valid[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; i++) valid[i] = pix0 + i * PSTEP < P;
+    EdgeData<VEC> ea, eb;
     const float* ix = img_xf + n * 16;
     float R[9], T[3];
 #pragma unroll
@@ -274,8 +297,6 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
     const float f = ix[12], ppx = ix[13], ppy = ix[14], shift = ix[15];
     const int W = imw[n], area = imarea[n];
     const float invW = 1.f / (float)W, inv_f = 1.f / f;
-    const int pix0 = chunk * CHUNK + (VEC ? tid * PXT : tid);       // pixel i of this thread: pix0 + i * PSTEP
-    constexpr int PSTEP = VEC ? 1 : TPB;
 
     // forward of the image side: depth -> camera point -> world point (optimizer.py:190-200,244-251)
     auto pixel_forward = [&](int i, float rawv, float monov, float& dep, float& ddp, float& gxm, float& gym, float* rel) {
@@ -303,15 +324,16 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
     };
 
     float raw[PXT], monov[PXT], proj[PXT][3], gp[PXT][3];
-    bool valid[PXT];
-#pragma unroll
-    for (int i = 0; i < PXT; i++) valid[i] = pix0 + i * PSTEP < P;
     if (VEC) {
         f32x4 r4 = {0.f, 0.f, 0.f, 0.f}, m4 = {0.f, 0.f, 0.f, 0.f};
         if (valid[0]) {
             r4 = *reinterpret_cast<const f32x4*>(d.depth + (size_t)n * P + pix0);
             if (MONO) m4 = *reinterpret_cast<const f32x4*>(d.mono + (size_t)n * P + pix0);
         }
+        // the first two edge sides are requested right behind the depth: the memory counter retires in order, so the forward
+        // arithmetic below waits for the depth alone and runs while the edge data is still on its way
+        if (kbeg < kend) load_edge(d, tb[3], P, pix0, valid, ea);
+        if (kbeg + 1 < kend) load_edge(d, tb[4], P, pix0, valid, eb);
         raw[0] = r4.x; raw[1] = r4.y; raw[2] = r4.z; raw[3] = r4.w;
         monov[0] = m4.x; monov[1] = m4.y; monov[2] = m4.z; monov[3] = m4.w;
     } else {
@@ -321,6 +343,8 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
             raw[i] = valid[i] ? d.depth[off] : 0.f;
             monov[i] = (MONO && valid[i]) ? d.mono[off] : 0.f;
         }
+        if (kbeg < kend) load_edge(d, tb[3], P, pix0, valid, ea);
+        if (kbeg + 1 < kend) load_edge(d, tb[4], P, pix0, valid, eb);
     }
 #pragma unroll
     for (int i = 0; i < PXT; i++) {
@@ -386,39 +410,53 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
                 acc[9] += g0; acc[10] += g1; acc[11] += g2;
             }
         }
+        if (MODE == 0) {
+            const float s = dpp_row_sum16(acc[12]);
+            if ((lane & 15) == 0) red[buf][kb][wave * 4 + (lane >> 4)][12] = s;
+        } else {
+            // the 13 sums of a 16-lane row by a reduce-scatter (common.h): 29 VALU operations and ONE 16-byte LDS store per quad
+            // instead of 13 four-step butterflies with a masked 4-byte store each -- this loop is bound by instruction issue
+            // (tools/align_stream_lab.hip: its access pattern alone streams at 6.3 TB/s), and the butterflies, their DPP wait
+            // states and the 13 exec-masked stores were a third of its instructions
+            float v16[16], u[4];
 #pragma unroll
-        for (int j = 0; j < 13; j++) {
-            if (MODE == 0 && j < 12) continue;
-            const float s = dpp_row_sum16(acc[j]);
-            if ((lane & 15) == 0) red[buf][kb][wave * 4 + (lane >> 4)][j] = s;
+            for (int j = 0; j < 13; j++) v16[j] = acc[j];
+            v16[13] = v16[14] = v16[15] = 0.f;
+            row_reduce_scatter16<13>(v16, u);
+            if ((lane & 3) == 0) *reinterpret_cast<f32x4*>(&red[buf][kb][wave * 4 + (lane >> 4)][lane & 12]) = f32x4{u[0], u[1], u[2], u[3]};
         }
     };
 
-    const int kbeg = inc_ptr[n], kend = inc_ptr[n + 1];
-    // The image's incidence codes go to LDS once: read from global memory inside the loop they are VECTOR loads (hipcc does not
-    // prove them uniform), and the s_waitcnt vmcnt(0) each one needs before its value can form the next address drains the
-    // edge data prefetched into the other register buffer -- one edge side in flight instead of two.  An LDS read waits on
-    // lgkmcnt and leaves the vector-memory queue alone; readfirstlane keeps the address arithmetic on the scalar unit.
-    // (a3r_align_create rejects graphs with more than MAX_INC edge sides per image)
+    // The incidence codes are read with SCALAR loads (a uniform index into a noalias table: s_load, counted on lgkmcnt): a vector
+    // load here would need s_waitcnt vmcnt(0) before its value could form the next address and would drain the edge data in flight.
+    // (Rounds 1-2 copied the image's codes to LDS first, which cost the prologue a vector load, an LDS pass and a barrier.)
+#ifndef A3R_ALIGN_SCALAR_CODES
+#define A3R_ALIGN_SCALAR_CODES 1
+#endif
+#if A3R_ALIGN_SCALAR_CODES
+    auto code_at = [&](int k) { return inc[__builtin_amdgcn_readfirstlane(k)]; };
+#else
     __shared__ int s_inc[MAX_INC];
     for (int i = tid; i < kend - kbeg; i += TPB) s_inc[i] = inc[kbeg + i];
     __syncthreads();
     auto code_at = [&](int k) { return __builtin_amdgcn_readfirstlane(s_inc[k - kbeg]); };
+#endif
     int buf = 0;
-    EdgeData<VEC> ea, eb;
-    if (kbeg < kend) load_edge(d, code_at(kbeg), P, pix0, valid, ea);
-    // one flat loop, two edge sides per trip; the LDS batch of EB slots is flushed inside
+    A3R_STAMP(1);
+    // one flat loop, two edge sides per trip, each register buffer re-requested right after it has been consumed (one edge side
+    // in flight behind the one being worked on); the LDS batch of EB slots is flushed inside
     int kb = 0, k0 = kbeg;
 #pragma unroll 1
     for (int k = kbeg; k < kend; k += 2) {
-        const int code0 = code_at(k);
         const bool has1 = k + 1 < kend;
-        const int code1 = has1 ? code_at(k + 1) : code0;
-        if (has1) load_edge(d, code1, P, pix0, valid, eb);          // in flight while `ea` is consumed
-        consume(code0, ea, buf, kb);
+        consume(code_at(k), ea, buf, kb);
+#ifdef A3R_ALIGN_STAMPS
+        if (k == kbeg) { asm volatile("" :: "v"(gp[0][0])); A3R_STAMP(2); }
+#endif
+        if (k + 2 < kend) load_edge(d, code_at(k + 2), P, pix0, valid, ea);
         if (has1) {
-            if (k + 2 < kend) load_edge(d, code_at(k + 2), P, pix0, valid, ea);
-            consume(code1, eb, buf, kb + 1);
+            consume(code_at(k + 1), eb, buf, kb + 1);
+            if (k + 3 < kend) load_edge(d, code_at(k + 3), P, pix0, valid, eb);
         }
         kb += 2;
         if (kb == EB || k + 2 >= kend) {
@@ -436,7 +474,15 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
             buf ^= 1; kb = 0; k0 += EB;
         }
     }
+    A3R_STAMP(3);
     if (MODE != 0) {
+    // the Adam moments of this thread's pixels are requested now: their latency runs under the per-image sums below
+    f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
+    if (VEC && MODE == 2 && valid[0]) {
+        const size_t off = (size_t)n * P + pix0;
+        m4 = *reinterpret_cast<const f32x4*>(d.adam_depth + off);
+        v4 = *reinterpret_cast<const f32x4*>(d.adam_depth + (size_t)d.N * P + off);
+    }
 
     // per-image sums and the per-pixel parameter (forward quantities are recomputed: cheaper than keeping them live)
     float accN[16], gout[PXT];
@@ -476,8 +522,6 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
                 f32x4 g4 = {gout[0], gout[1], gout[2], gout[3]};
                 *reinterpret_cast<f32x4*>(g_depth + off) = g4;
             } else {
-                f32x4 m4 = *reinterpret_cast<const f32x4*>(d.adam_depth + off);
-                f32x4 v4 = *reinterpret_cast<const f32x4*>(d.adam_depth + NP + off);
                 float pm[4] = {m4.x, m4.y, m4.z, m4.w}, pv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4];
 #pragma unroll
                 for (int i = 0; i < PXT; i++) { pp[i] = raw[i]; adam_update(pp[i], gout[i], pm[i], pv[i], ad); }
@@ -501,11 +545,12 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
             }
         }
     }
+    A3R_STAMP(4);
     __syncthreads();   // red[] may still be read by the last batch
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const float s = dpp_row_sum16(accN[j]);
-        if ((lane & 15) == 0) red[0][0][wave * 4 + (lane >> 4)][j] = s;
+    {
+        float u[4];
+        row_reduce_scatter16<16>(accN, u);
+        if ((lane & 3) == 0) *reinterpret_cast<f32x4*>(&red[0][0][wave * 4 + (lane >> 4)][lane & 12]) = f32x4{u[0], u[1], u[2], u[3]};
     }
     __syncthreads();
     if (tid < 4) {
@@ -515,6 +560,15 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
         store16_wt(d.partN, (unsigned)(((size_t)n * d.nchunks + chunk) * 64 + 16 * tid), s4);
     }
     }   // MODE != 0
+#ifdef A3R_ALIGN_STAMPS
+    A3R_STAMP(5);
+    if (tid == 0 && MODE == 2) {
+        unsigned long long* o = g_align_stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 8192 * 8;
+        for (int i = 0; i < 6; i++) o[i] = stamp[i];
+        o[6] = (unsigned long long)(kend - kbeg);
+        o[7] = ((unsigned long long)n << 32) | (unsigned)chunk;
+    }
+#endif
     if (!d.fused_tail) return;
 
     // ---- tail of the iteration inside this launch (no finalize launches): last-block-done tickets, two levels.
@@ -1083,7 +1137,7 @@ static size_t ws_layout(int E, int N, int P, size_t* off /*[17]*/) {
     off[13] = take((size_t)2 * E * 16 * 4);         // sumE
     off[14] = take((size_t)N * 16 * 4);             // sumN
     off[15] = take((size_t)(N + 1) * 4);            // tick
-    off[16] = take((size_t)N * 4);                  // order
+    off[16] = take((size_t)N * 8 * 4);              // order: per dispatch slot {image, kbeg, kend, code0, code1, 0, 0, 0}
     return o;
 }
 
@@ -1148,7 +1202,14 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
     std::vector<int> order(s->N);
     for (int n = 0; n < s->N; n++) order[n] = n;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deg[x + 1] - deg[x] > deg[y + 1] - deg[y]; });
-    if (err == hipSuccess) err = up(off[16], order.data(), s->N * 4);
+    std::vector<int> tab((size_t)s->N * 8, 0);
+    for (int y = 0; y < s->N; y++) {
+        const int n = order[y], kb = deg[n], ke = deg[n + 1];
+        tab[y * 8 + 0] = n; tab[y * 8 + 1] = kb; tab[y * 8 + 2] = ke;
+        tab[y * 8 + 3] = kb < ke ? inc[kb] : 0;
+        tab[y * 8 + 4] = kb + 1 < ke ? inc[kb + 1] : 0;
+    }
+    if (err == hipSuccess) err = up(off[16], tab.data(), tab.size() * 4);
     if (err == hipSuccess) err = hipMemsetAsync(ws + off[15], 0, (size_t)(s->N + 1) * 4, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);   // host vectors go out of scope
     if (err != hipSuccess) {
@@ -1404,6 +1465,14 @@ extern "C" int a3r_align_invalidate(a3r_align_t a) {
     a->dirty = true;
     return A3R_OK;
 }
+
+#ifdef A3R_ALIGN_STAMPS
+extern "C" int a3r_debug_align_stamps(unsigned long long* host, int n_words) {
+    A3R_HIP(hipDeviceSynchronize());
+    A3R_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_align_stamps), (size_t)n_words * 8));
+    return A3R_OK;
+}
+#endif
 
 extern "C" int a3r_align_steps_done(a3r_align_t a) { return a ? a->steps : -1; }
 

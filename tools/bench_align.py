@@ -44,7 +44,9 @@ def run(N, H, W, graph, mono, iters=100, flow=False):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
-    if which == "small":
+    if which == "one":
+        run(16, 384, 512, "swin-3-noncyclic", False)
+    elif which == "small":
         run(16, 384, 512, "swin-3-noncyclic", False)
         run(16, 384, 512, "swin-3-noncyclic", True)
         run(32, 288, 512, "complete", False, iters=30)
