@@ -13,7 +13,7 @@ import sys
 KEYS = {"gemm_bf3_kernel<0": "gemm_bf3_kernel", "gemm_bf3_kernel<1": "gemm_bf3_kernel<1>", "attn_bf3_kernel": "attn_bf3_kernel",
         "gemm_kernel<0": "gemm_kernel<0>", "gemm_kernel<1": "gemm_kernel<1>", "attn_kernel": "attn_kernel",
         "align_main_kernel": "align_main_kernel", "layernorm_kernel": "layernorm_kernel", "layernorm_pair_kernel": "layernorm_kernel",
-        "layernorm_fh2_kernel": "layernorm_fh2_kernel", "attn_fh2_kernel": "attn_fh2_kernel", "upsample2x_kernel": "upsample2x_kernel",
+        "layernorm_fh2_kernel": "layernorm_fh2_kernel", "attn_fh2_kernel": "attn_fh2_kernel", "attn_fh2_v2_kernel": "attn_fh2_kernel", "upsample2x_kernel": "upsample2x_kernel",
         "head_final_kernel": "head_final_kernel", "head_final128_kernel": "head_final_kernel"}
 
 
