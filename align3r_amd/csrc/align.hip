@@ -27,7 +27,12 @@ namespace a3r {
 constexpr int PXT = 4;                 // pixels per thread
 constexpr int TPB = 256;
 constexpr int CHUNK = PXT * TPB;       // pixels per workgroup
-constexpr int EB = 8;                  // (edge,side) entries per LDS reduction batch
+// register buffers of raw edge data per thread: 2 (one edge side in flight behind the one being consumed; fits four waves per SIMD)
+// or 3 (two in flight; lab variant, needs A3R_ALIGN_MIN_WAVES=3)
+#ifndef A3R_ALIGN_NBUF
+#define A3R_ALIGN_NBUF 2
+#endif
+constexpr int EB = A3R_ALIGN_NBUF == 3 ? 9 : 8;   // (edge,side) entries per LDS reduction batch (a multiple of the buffers)
 constexpr int MAX_INC = 2048;          // edge sides incident to one image (their codes sit in LDS: 8 KB)
 constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.9f, ADAM_EPS = 1e-8f;  // base_opt.py:435
 
@@ -287,6 +292,9 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
 #pragma unroll
     for (int i = 0; i < PXT; i++) valid[i] = pix0 + i * PSTEP < P;
     EdgeData<VEC> ea, eb;
+#if A3R_ALIGN_NBUF == 3
+    EdgeData<VEC> ec;
+#endif
     const float* ix = img_xf + n * 16;
     float R[9], T[3];
 #pragma unroll
@@ -334,6 +342,9 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
         // arithmetic below waits for the depth alone and runs while the edge data is still on its way
         if (kbeg < kend) load_edge(d, tb[3], P, pix0, valid, ea);
         if (kbeg + 1 < kend) load_edge(d, tb[4], P, pix0, valid, eb);
+#if A3R_ALIGN_NBUF == 3
+        if (kbeg + 2 < kend) load_edge(d, tb[5], P, pix0, valid, ec);
+#endif
         raw[0] = r4.x; raw[1] = r4.y; raw[2] = r4.z; raw[3] = r4.w;
         monov[0] = m4.x; monov[1] = m4.y; monov[2] = m4.z; monov[3] = m4.w;
     } else {
@@ -345,6 +356,9 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
         }
         if (kbeg < kend) load_edge(d, tb[3], P, pix0, valid, ea);
         if (kbeg + 1 < kend) load_edge(d, tb[4], P, pix0, valid, eb);
+#if A3R_ALIGN_NBUF == 3
+        if (kbeg + 2 < kend) load_edge(d, tb[5], P, pix0, valid, ec);
+#endif
     }
 #pragma unroll
     for (int i = 0; i < PXT; i++) {
@@ -447,19 +461,25 @@ __global__ __launch_bounds__(TPB, VEC ? A3R_ALIGN_MIN_WAVES : 2) void align_main
     // in flight behind the one being worked on); the LDS batch of EB slots is flushed inside
     int kb = 0, k0 = kbeg;
 #pragma unroll 1
-    for (int k = kbeg; k < kend; k += 2) {
+    for (int k = kbeg; k < kend; k += A3R_ALIGN_NBUF) {
         const bool has1 = k + 1 < kend;
         consume(code_at(k), ea, buf, kb);
 #ifdef A3R_ALIGN_STAMPS
         if (k == kbeg) { asm volatile("" :: "v"(gp[0][0])); A3R_STAMP(2); }
 #endif
-        if (k + 2 < kend) load_edge(d, code_at(k + 2), P, pix0, valid, ea);
+        if (k + A3R_ALIGN_NBUF < kend) load_edge(d, code_at(k + A3R_ALIGN_NBUF), P, pix0, valid, ea);
         if (has1) {
             consume(code_at(k + 1), eb, buf, kb + 1);
-            if (k + 3 < kend) load_edge(d, code_at(k + 3), P, pix0, valid, eb);
+            if (k + 1 + A3R_ALIGN_NBUF < kend) load_edge(d, code_at(k + 1 + A3R_ALIGN_NBUF), P, pix0, valid, eb);
         }
-        kb += 2;
-        if (kb == EB || k + 2 >= kend) {
+#if A3R_ALIGN_NBUF == 3
+        if (k + 2 < kend) {
+            consume(code_at(k + 2), ec, buf, kb + 2);
+            if (k + 5 < kend) load_edge(d, code_at(k + 5), P, pix0, valid, ec);
+        }
+#endif
+        kb += A3R_ALIGN_NBUF;
+        if (kb == EB || k + A3R_ALIGN_NBUF >= kend) {
             __syncthreads();
             if (tid < EB * 4) {
                 // one 16-byte quarter of a slot's row per thread, rows r added in order (the row is handed to the image's last workgroup)
@@ -1137,7 +1157,7 @@ static size_t ws_layout(int E, int N, int P, size_t* off /*[17]*/) {
     off[13] = take((size_t)2 * E * 16 * 4);         // sumE
     off[14] = take((size_t)N * 16 * 4);             // sumN
     off[15] = take((size_t)(N + 1) * 4);            // tick
-    off[16] = take((size_t)N * 8 * 4);              // order: per dispatch slot {image, kbeg, kend, code0, code1, 0, 0, 0}
+    off[16] = take((size_t)N * 8 * 4);              // order: per dispatch slot {image, kbeg, kend, code0, code1, code2, 0, 0}
     return o;
 }
 
@@ -1208,6 +1228,7 @@ extern "C" int a3r_align_create(const a3r_align_desc* s, a3r_align_t* out, void*
         tab[y * 8 + 0] = n; tab[y * 8 + 1] = kb; tab[y * 8 + 2] = ke;
         tab[y * 8 + 3] = kb < ke ? inc[kb] : 0;
         tab[y * 8 + 4] = kb + 1 < ke ? inc[kb + 1] : 0;
+        tab[y * 8 + 5] = kb + 2 < ke ? inc[kb + 2] : 0;
     }
     if (err == hipSuccess) err = up(off[16], tab.data(), tab.size() * 4);
     if (err == hipSuccess) err = hipMemsetAsync(ws + off[15], 0, (size_t)(s->N + 1) * 4, st);
