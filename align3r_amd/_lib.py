@@ -100,6 +100,7 @@ SIGNATURES = {
     "a3r_layernorm_fh2": (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, C.c_float, c_void, c_void]),
     "a3r_linear_fh2_grouped": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
     "a3r_linear_fh2": (C.c_int, [c_void, c_void, C.c_float, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Epilogue), c_void]),
+    "a3r_attention_fh2_set_form": (C.c_int, [C.c_int]),
     "a3r_attention_fh2": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Fh2AttnRange), c_void]),
     "a3r_attention_bf3_fh2out": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_bf3_bytes": (C.c_size_t, [C.c_long, C.c_int]),

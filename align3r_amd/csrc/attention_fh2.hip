@@ -14,6 +14,7 @@
 #include "common.h"
 #include "fh2.h"
 #include <cmath>
+#include <atomic>
 #include <cstdlib>
 #include <string>
 
@@ -459,8 +460,16 @@ __global__ __launch_bounds__(A4T, 3) void attn_fh2_v2_kernel(Attn4Args a) {
     fh2_publish_block(a.out_absmax, amax, s_amax);
 }
 
+// which kernel form a3r_attention_fh2 launches: 2 (default) or 1 (A3R_ATTN=v1 / a3r_attention_fh2_set_form)
+static std::atomic<int> g_attn_form{(getenv("A3R_ATTN") && std::string(getenv("A3R_ATTN")) == "v1") ? 1 : 2};
+
 }  // namespace a3r
 using namespace a3r;
+
+extern "C" int a3r_attention_fh2_set_form(int form) {
+    A3R_CHECK_ARG(form == 1 || form == 2, "a3r_attention_fh2_set_form: form must be 1 or 2");
+    return g_attn_form.exchange(form) ;
+}
 
 extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ldk, const void* v2, int ldv, void* o2, int ldo,
                                  int B, int H, int Nq, int Nk, const a3r_fh2_attn_range* range, void* stream) {
@@ -476,7 +485,7 @@ extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ld
     A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_fh2: row strides must be multiples of 8");
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q2) | reinterpret_cast<uintptr_t>(k2) | reinterpret_cast<uintptr_t>(v2) |
                     reinterpret_cast<uintptr_t>(o2)) & 15) == 0, "a3r_attention_fh2: pointers must be 16-byte aligned");
-    static const bool v1 = getenv("A3R_ATTN") && std::string(getenv("A3R_ATTN")) == "v1";      // A/B switch: the register-staged V form
+    const bool v1 = g_attn_form.load(std::memory_order_relaxed) == 1;      // A/B switch: the register-staged V form
     static PerDeviceOnce attr_once;
     A3R_HIP(attr_once.ensure([&] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);

@@ -279,6 +279,10 @@ typedef struct {
 } a3r_fh2_attn_range;
 int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ldk, const void* v2, int ldv, void* o2, int ldo,
                       int B, int H, int Nq, int Nk, const a3r_fh2_attn_range* range, void* stream);
+/* Kernel form behind a3r_attention_fh2: 2 (default: K and V tiles by LDS-DMA, transposed LDS reads) or 1 (round 2: V staged through
+ * registers); the results are bitwise equal (tests/test_gpu_fh2.py).  Returns the previous form, or a negative error code.
+ * Process-wide; environment A3R_ATTN=v1 selects form 1 at start-up.  A development switch, not part of the reference's interface. */
+int a3r_attention_fh2_set_form(int form);
 
 /* cos/sin tables [max_pos, 16] for head_dim 64 computed like RoPE2D.get_cos_sin (pos_embed.py:118-128);
  * HOST buffers. */

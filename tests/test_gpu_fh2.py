@@ -119,6 +119,29 @@ def test_attention_fh2(ops, B, H, Nq, Nk):
         assert torch.equal(o2b.data, o2.data)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 1, 32, 64), (2, 3, 196, 196), (2, 2, 100, 37), (1, 2, 300, 65), (3, 12, 197, 333), (2, 16, 768, 768)])
+def test_attention_fh2_forms_are_bitwise_equal(ops, B, H, Nq, Nk):
+    """The second kernel form (K and V by LDS-DMA, V's transposed operand by ds_read_b64_tr_b16, prefetched fragments) against the
+    round-2 form (V staged through registers): the same products in the same order, so every output byte is equal -- ragged query
+    and key counts, operand scales and the range statistic included."""
+    from align3r_amd import _lib
+    lib = _lib.load()
+    D = H * 64
+    q, kv = ops.split_fh2(rnd(B * Nq, D, seed=5), scale=4.0), ops.split_fh2(rnd(B * Nk, 2 * D, seed=6), scale=0.5)
+    outs = []
+    prev = lib.a3r_attention_fh2_set_form(2)
+    try:
+        for form in (1, 2):
+            assert lib.a3r_attention_fh2_set_form(form) >= 1
+            am = ops.absmax_word(q.data.device)
+            o = ops.attention_fh2(q, kv, kv, B, H, Nq, Nk, q_col=0, k_col=0, v_col=D, out_scale=2.0, out_absmax=am)
+            outs.append((o.data.clone(), ops.absmax_value(am)))
+    finally:
+        lib.a3r_attention_fh2_set_form(prev if prev in (1, 2) else 2)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1] and outs[0][1] > 0
+
+
 def test_linear_fh2_rope_to_fh2(ops):
     """The q / k projection epilogue: RoPE-2D on the leading columns, written in fh2 form, against the fp32-output epilogue of the same
     kernel and against the exact-fp32 MFMA GEMM's."""
