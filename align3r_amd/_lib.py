@@ -105,6 +105,7 @@ SIGNATURES = {
     "a3r_attention_bf3_fh2out": (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "a3r_bf3_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "a3r_bf3_set_products": (C.c_int, [C.c_int]),
+    "a3r_fh2_set_passes": (C.c_int, [C.c_int]),
     "a3r_split_bf3": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),
     "a3r_bf3_w_bytes": (C.c_size_t, [C.c_long, C.c_int]),
     "a3r_split_bf3_w": (C.c_int, [c_void, C.c_int, c_void, C.c_long, C.c_int, c_void]),

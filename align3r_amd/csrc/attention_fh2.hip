@@ -19,6 +19,7 @@
 #include <string>
 
 namespace a3r {
+int fh2_passes();      // gemm_fh2.hip: 3 (default) or 1 (a3r_fh2_set_passes)
 
 constexpr int A4T = 256;                    // threads per workgroup (4 waves, 32 queries each)
 constexpr int A4Q = 128;                    // queries per workgroup
@@ -270,7 +271,10 @@ __device__ __forceinline__ b4_s16x4 b4_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) b4_s16x4*)(p));
 }
 
+// PASSES 1 (a3r_fh2_set_passes(1)): first planes only -- q0 k0 and v0 p0 with p rounded to one fp16 -- the 16-bit operand mode.
+template <int PASSES>
 __global__ __launch_bounds__(A4T, 3) void attn_fh2_v2_kernel(Attn4Args a) {
+    constexpr int NPL = PASSES == 1 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                // [2][64 keys][256 B]
     char* Vs = smem + 2 * B4_TILE;                  // [64 keys][256 B]
@@ -285,13 +289,13 @@ __global__ __launch_bounds__(A4T, 3) void attn_fh2_v2_kernel(Attn4Args a) {
     const int q_row = qb * A4Q + wave * 32 + qi;
     const int q_ld = q_row < a.Nq ? q_row : a.Nq - 1;
 
-    f16x8 qf[4][2];
+    f16x8 qf[4][NPL];
     {
         const char* qp = a.q + ((size_t)b * a.Nq + q_ld) * a.pq + h * 256;
 #pragma unroll
         for (int s = 0; s < 4; s++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) qf[s][p] = *reinterpret_cast<const f16x8*>(qp + ((2 * s + half) * 2 + p) * 16);
+            for (int p = 0; p < NPL; p++) qf[s][p] = *reinterpret_cast<const f16x8*>(qp + ((2 * s + half) * 2 + p) * 16);
     }
     // ---- DMA: slot u = tid + 256 i -> (row = (tid >> 4) + 16 i, physical chunk tid & 15); swz(row) does not depend on i
     const int drow = tid >> 4;
@@ -351,18 +355,20 @@ __global__ __launch_bounds__(A4T, 3) void attn_fh2_v2_kernel(Attn4Args a) {
             f32x16 s;
 #pragma unroll
             for (int e = 0; e < 16; e++) s[e] = 0.f;
-            f16x8 kf[2][2];
+            f16x8 kf[2][NPL];
 #pragma unroll
-            for (int p = 0; p < 2; p++) kf[0][p] = *reinterpret_cast<const f16x8*>(Kt + kb * 32 * B4_ROW + koff[0][p]);
+            for (int p = 0; p < NPL; p++) kf[0][p] = *reinterpret_cast<const f16x8*>(Kt + kb * 32 * B4_ROW + koff[0][p]);
 #pragma unroll
             for (int st = 0; st < 4; st++) {
                 if (st < 3) {
 #pragma unroll
-                    for (int p = 0; p < 2; p++) kf[(st + 1) & 1][p] = *reinterpret_cast<const f16x8*>(Kt + kb * 32 * B4_ROW + koff[st + 1][p]);
+                    for (int p = 0; p < NPL; p++) kf[(st + 1) & 1][p] = *reinterpret_cast<const f16x8*>(Kt + kb * 32 * B4_ROW + koff[st + 1][p]);
                 }
                 B4_PIN();
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][1], qf[st][0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][0], qf[st][1], s, 0, 0, 0);
+                if constexpr (PASSES == 3) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][NPL - 1], qf[st][0], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][0], qf[st][NPL - 1], s, 0, 0, 0);
+                }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st & 1][0], qf[st][0], s, 0, 0, 0);
                 B4_PIN();
             }
@@ -403,35 +409,38 @@ __global__ __launch_bounds__(A4T, 3) void attn_fh2_v2_kernel(Attn4Args a) {
                 __syncthreads();
             }
             // ---- O^T += V^T P^T; the transposed V fragments of the next (s2, db) are requested before the current MFMAs
-            a4_u32x4 pf[2][2];
+            a4_u32x4 pf[2][NPL];
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                 for (int mm = 0; mm < 4; mm++) {
                     uint32_t p0, p1;
-                    fh2_split2(s[8 * s2 + 2 * mm], s[8 * s2 + 2 * mm + 1], p0, p1);
-                    pf[s2][0][mm] = p0; pf[s2][1][mm] = p1;
+                    fh2_split2(s[8 * s2 + 2 * mm], s[8 * s2 + 2 * mm + 1], p0, p1);       // (PASSES 1: the residual plane is dead code)
+                    pf[s2][0][mm] = p0;
+                    if constexpr (PASSES == 3) pf[s2][NPL - 1][mm] = p1;
                 }
-            auto vread = [&](int step, b4_s16x8 (&vf)[2]) {             // step = 2 s2 + db
+            auto vread = [&](int step, b4_s16x8 (&vf)[NPL]) {           // step = 2 s2 + db
                 const int s2 = step >> 1, db = step & 1;
                 const char* base = Vs + (kb * 32 + s2 * 16) * B4_ROW;
 #pragma unroll
-                for (int p = 0; p < 2; p++) {
+                for (int p = 0; p < NPL; p++) {
                     const b4_s16x4 lo = b4_tr_read(base + voff[p][db][0]), hi = b4_tr_read(base + voff[p][db][1]);
                     vf[p] = b4_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
             };
-            b4_s16x8 vf[2][2];
+            b4_s16x8 vf[2][NPL];
             vread(0, vf[0]);
 #pragma unroll
             for (int step = 0; step < 4; step++) {
                 if (step < 3) vread(step + 1, vf[(step + 1) & 1]);
                 B4_PIN();
                 const int s2 = step >> 1, db = step & 1;
-                const f16x8 b0 = __builtin_bit_cast(f16x8, pf[s2][0]), b1 = __builtin_bit_cast(f16x8, pf[s2][1]);
-                const f16x8 v0 = __builtin_bit_cast(f16x8, vf[step & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[step & 1][1]);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0, oacc[db], 0, 0, 0);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b1, oacc[db], 0, 0, 0);
+                const f16x8 b0 = __builtin_bit_cast(f16x8, pf[s2][0]), b1 = __builtin_bit_cast(f16x8, pf[s2][NPL - 1]);
+                const f16x8 v0 = __builtin_bit_cast(f16x8, vf[step & 1][0]), v1 = __builtin_bit_cast(f16x8, vf[step & 1][NPL - 1]);
+                if constexpr (PASSES == 3) {
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, b0, oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b1, oacc[db], 0, 0, 0);
+                }
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, b0, oacc[db], 0, 0, 0);
                 B4_PIN();
             }
@@ -485,11 +494,12 @@ extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ld
     A3R_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "a3r_attention_fh2: row strides must be multiples of 8");
     A3R_CHECK_ARG(((reinterpret_cast<uintptr_t>(q2) | reinterpret_cast<uintptr_t>(k2) | reinterpret_cast<uintptr_t>(v2) |
                     reinterpret_cast<uintptr_t>(o2)) & 15) == 0, "a3r_attention_fh2: pointers must be 16-byte aligned");
-    const bool v1 = g_attn_form.load(std::memory_order_relaxed) == 1;      // A/B switch: the register-staged V form
+    const bool v1 = g_attn_form.load(std::memory_order_relaxed) == 1 && fh2_passes() == 3;      // A/B switch: the register-staged V form
     static PerDeviceOnce attr_once;
     A3R_HIP(attr_once.ensure([&] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_v2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fh2_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, B4_LDS_BYTES);
         return e;
     }));
     Attn4Args a = {static_cast<const char*>(q2), static_cast<const char*>(k2), static_cast<const char*>(v2), static_cast<char*>(o2),
@@ -499,7 +509,8 @@ extern "C" int a3r_attention_fh2(const void* q2, int ldq, const void* k2, int ld
     dim3 grid(8 * ((groups + 7) / 8) * nqb);
     ProfScope prof(PK_ATTENTION_FH2, 4.0 * B * H * (double)Nq * Nk * 64, as_stream(stream));
     if (v1) hipLaunchKernelGGL(attn_fh2_kernel, grid, dim3(A4T), A4_LDS_BYTES, as_stream(stream), a);
-    else hipLaunchKernelGGL(attn_fh2_v2_kernel, grid, dim3(A4T), B4_LDS_BYTES, as_stream(stream), a);
+    else if (fh2_passes() == 1) hipLaunchKernelGGL(attn_fh2_v2_kernel<1>, grid, dim3(A4T), B4_LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL(attn_fh2_v2_kernel<3>, grid, dim3(A4T), B4_LDS_BYTES, as_stream(stream), a);
     A3R_LAUNCH_CHECK();
     return A3R_OK;
 }

@@ -215,7 +215,10 @@ __device__ __forceinline__ void fh2_epilogue_head(const GemmArgs& g, const Group
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL, int AMODE = 0>
+// PASSES 3: the fp32-grade product h0 g0 + h0 g1 + h1 g0.  PASSES 1 (a3r_fh2_set_passes(1), the 16-bit operand mode): h0 g0 alone --
+// plain fp16 operands (11 significant bits, inside fp16's range by the same per-site scales), fp32 accumulation; the second planes
+// are neither read from LDS nor multiplied.
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, int AMODE = 0, int PASSES = 3>
 __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4) void gemm_fh2_kernel(Fh2Args fa) {
     const GemmArgs& g = fa.g;
     constexpr int NT = WM * WN * 64, U = 8;
@@ -345,17 +348,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
     for (int t = 0; t < npro; t++) issue(t, t);
     fh2_wait_vmcnt_dyn((npro - 1) * LPS);
     __builtin_amdgcn_s_barrier();
-    f16x8 af[TM][2], bfr[2][TN][2];
+    constexpr int NPL = PASSES == 1 ? 1 : 2;                   // operand planes that are read
+    f16x8 af[TM][NPL], bfr[2][TN][NPL];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) af[i][p] = *reinterpret_cast<const f16x8*>(smem + offA[p] + i * 16 * U * 16);
+        for (int p = 0; p < NPL; p++) af[i][p] = *reinterpret_cast<const f16x8*>(smem + offA[p] + i * 16 * U * 16);
 #pragma unroll
     for (int j = 0; j < TN; j++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) bfr[0][j][p] = *reinterpret_cast<const f16x8*>(smem + offB[p] + j * 16 * U * 16);
+        for (int p = 0; p < NPL; p++) bfr[0][j][p] = *reinterpret_cast<const f16x8*>(smem + offB[p] + j * 16 * U * 16);
     int nbuf = 1 % NS;                                         // ring slot of stage kt + 1
-    auto kstep = [&](int kt, f16x8 (&bc)[TN][2], f16x8 (&bn)[TN][2], auto has_next) {
+    auto kstep = [&](int kt, f16x8 (&bc)[TN][NPL], f16x8 (&bn)[TN][NPL], auto has_next) {
         constexpr bool NEXT = decltype(has_next)::value;
         const char* sb = smem + nbuf * STAGE;
         if constexpr (NEXT) {
@@ -367,9 +371,21 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int p = 0; p < 2; p++) bn[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
+                for (int p = 0; p < NPL; p++) bn[j][p] = *reinterpret_cast<const f16x8*>(sb + offB[p] + j * 16 * U * 16);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PASSES == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][0], bc[j][0], acc[i][j], 0, 0, 0);
+                if constexpr (NEXT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    af[i][0] = *reinterpret_cast<const f16x8*>(sb + offA[0] + i * 16 * U * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             // per accumulator the terms are added smallest first (x1 w0, x0 w1, x0 w0); across the row's accumulators the products of the
@@ -390,6 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 2048 ? 2 : 4)
                 af[i][0] = *reinterpret_cast<const f16x8*>(sb + offA[0] + i * 16 * U * 16);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     };
@@ -491,9 +508,13 @@ static int choose_fh2_tile(int M, int N, int groups) {
     return best_t;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FULL, int AMODE = 0>
+// process-wide arithmetic mode of the fh2 matrix kernels (a3r_fh2_set_passes): 3 (fp32-grade, default) or 1 (fp16 operands)
+static int g_fh2_passes = 3;
+int fh2_passes() { return g_fh2_passes; }
+
+template <int BM, int BN, int WM, int WN, int NS, bool FULL, int AMODE = 0, int PASSES = 3>
 static int launch_fh2_variant(const Fh2Args& fa, hipStream_t st) {
-    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, AMODE>;
+    auto kern = gemm_fh2_kernel<BM, BN, WM, WN, NS, FULL, AMODE, PASSES>;
     constexpr int ring = NS * (BM + BN) * 128, epi = WM * WN * epi_lds_wave_bytes(BM / WM), lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static PerDeviceOnce attr_once;
@@ -509,7 +530,8 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     g.direct_epilogue = 0;
     static const int gm_env = getenv("A3R_FH2_GM") ? atoi(getenv("A3R_FH2_GM")) : 0;
     int t = choose_fh2_tile(g.M, g.N, g.groups);
-    if ((AMODE == 1 || g.epi.epi == A3R_EPI_HEAD) && t != 0) t = 2;   // the implicit conv and the HEAD epilogue are built for tiles 0 and 2
+    if ((AMODE == 1 || g.epi.epi == A3R_EPI_HEAD) && t != 0) t = 2;
+    if (g_fh2_passes == 1) t = 2;   // the implicit conv and the HEAD epilogue are built for tiles 0 and 2
     const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -527,6 +549,8 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     if (t == 0) {
         return full ? launch_fh2_variant<256, 128, 4, 4, 3, true, AMODE>(fa, st) : launch_fh2_variant<256, 128, 4, 4, 3, false, AMODE>(fa, st);
     }
+    if (g_fh2_passes == 1)      // the 16-bit operand mode runs every shape on the 128x128 tile
+        return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, AMODE, 1>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, AMODE, 1>(fa, st);
     if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, AMODE>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, AMODE>(fa, st);
     if constexpr (AMODE == 0) {
         if (t == 3) return full ? launch_fh2_variant<256, 128, 4, 2, 3, true>(fa, st) : launch_fh2_variant<256, 128, 4, 2, 3, false>(fa, st);
@@ -553,6 +577,12 @@ static float fh2_acc_factor(const a3r_epilogue& e, float w_scale, float xs, floa
 
 }  // namespace a3r
 using namespace a3r;
+
+extern "C" int a3r_fh2_set_passes(int passes) {
+    const int prev = g_fh2_passes;
+    if (passes == 3 || passes == 1) g_fh2_passes = passes;
+    return prev;
+}
 
 extern "C" size_t a3r_fh2_bytes(long rows, int K) { return rows > 0 && K > 0 ? (size_t)rows * K * 4 : 0; }
 

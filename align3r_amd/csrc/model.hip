@@ -64,6 +64,7 @@ struct a3r_model_s {
     std::map<std::string, std::pair<const float*, size_t>> taps;
     // nn.Linear weights also kept in bf3 form (gemm_bf3.hip) unless A3R_GEMM=f32: fp32 pointer -> bf3 twin in `packed`
     bool use_bf3 = true;
+    int fh2_passes = 3;       // fh2 matrix passes per product: 3 = fp32-grade; A3R_GEMM=f16 -> 1 (plain fp16 operands, reduced precision)
     int products = 6;         // bf3 plane products per multiply: 6 = fp32-accurate; A3R_GEMM=bf3x3 -> 3, A3R_GEMM=bf16 -> 1 (reduced precision)
     std::map<const float*, const void*> w3;
     // transformer nn.Linear weights in fh2 form (two fp16 planes, gemm_fh2.hip) unless A3R_GEMM names another mode:
@@ -103,9 +104,11 @@ extern "C" int a3r_model_create(const a3r_model_config* cfg, a3r_model_t* out) {
         const std::string mode(e);
         // f32: exact-fp32 MFMA kernels; bf3: every GEMM on the exact three-plane bf16 form (6 passes); bf3x3 / bf16: reduced-precision
         // bf3 modes; anything else (default, "fh2"): transformer GEMMs on the two-plane fp16 form (3 passes), DPT convs / attention on bf3
+        // f16: the fh2 kernels with ONE pass per product (plain fp16 operands under the same range control): the fast 16-bit mode
         m->use_bf3 = mode != "f32";
         m->products = mode == "bf16" ? 1 : mode == "bf3x3" ? 3 : 6;
         m->use_fh2 = !(mode == "f32" || mode == "bf3" || mode == "bf3x3" || mode == "bf16");
+        m->fh2_passes = mode == "f16" ? 1 : 3;
     }
     if (const char* e = getenv("A3R_CONV")) m->conv_fh2 = std::string(e) != "bf3";
     m->conv_fh2 = m->conv_fh2 && m->use_bf3 && m->use_fh2;
@@ -860,6 +863,11 @@ int run_plan(a3r_model_s* m, bool dry, const float* img1, const float* img2, con
         ProductsGuard(bool on_, int p) : prev(6), on(on_) { if (on) prev = a3r_bf3_set_products(p); }
         ~ProductsGuard() { if (on) a3r_bf3_set_products(prev); }
     } products_guard(!dry && m->use_bf3, m->products);
+    struct PassesGuard {
+        int prev; bool on;
+        PassesGuard(bool on_, int p) : prev(3), on(on_) { if (on) prev = a3r_fh2_set_passes(p); }
+        ~PassesGuard() { if (on) a3r_fh2_set_passes(prev); }
+    } passes_guard(!dry && m->use_bf3 && m->use_fh2, m->fh2_passes);
     Plan P;
     P.m = m; P.stream = stream; P.phase = phase;
     if (!dry && m->use_bf3 && m->use_fh2) {

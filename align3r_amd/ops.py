@@ -131,6 +131,11 @@ def bf3_set_products(n: int) -> int:
     return int(_lib.load().a3r_bf3_set_products(int(n)))
 
 
+def fh2_set_passes(n: int) -> int:
+    """Arithmetic mode of the fh2 kernels: 3 (fp32-grade, default) or 1 (plain fp16 operands).  Returns the previous mode."""
+    return int(_lib.load().a3r_fh2_set_passes(int(n)))
+
+
 class Bf3:
     """An fp32 matrix [rows, K] in bf3 form (three exact bf16 planes, include/a3r.h): uint8 storage + logical shape."""
 

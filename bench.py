@@ -346,38 +346,42 @@ def main():
     # rules as the headline; its stated tolerances (asserted by tests/test_gpu_bf16_mode.py, frozen in round 2): tensor-max 5e-2,
     # per-point p99 2e-1 against the fp32 oracle, ATE / extent 1e-2 and 6 degrees at pose level.
     if not a.no_bf16_run and world == 1:
-        try:
-            prev = os.environ.get("A3R_GEMM")
-            os.environ["A3R_GEMM"] = "bf16"
+        # two 16-bit operand modes: "bf16" (the bf3 kernels with the first plane product alone: plain bf16 operands) and "f16" (the
+        # fh2 kernels with ONE pass: plain fp16 operands, three more mantissa bits, under the default path's range control)
+        for mode, key, kern, what in (("bf16", "bf16_mode", "gemm_bf3_kernel (linear, split-bf16 MFMA)", "one bf16 MFMA pass per product"),
+                                      ("f16", "f16_mode", "gemm_fh2_kernel (linear, split-fp16 MFMA)", "one fp16 MFMA pass per product (a3r_fh2_set_passes(1))")):
             try:
-                eng16 = PairEngine(VITL, sd, dev)       # the arithmetic mode is read when the handle is created
-            finally:
-                if prev is None:
-                    os.environ.pop("A3R_GEMM", None)
-                else:
-                    os.environ["A3R_GEMM"] = prev
-            eng16.forward(*inputs[0], out=out)
-            torch.cuda.synchronize()
-            _lib.prof_enable(True)
-            t0 = time.perf_counter()
-            n16 = 2
-            for s in range(n16):
-                eng16.forward(*inputs[s % n_batches], out=out)
-            torch.cuda.synchronize()
-            dt16 = time.perf_counter() - t0
-            _lib.prof_enable(False)
-            p16 = {p["name"]: p for p in _lib.prof_report()}
-            g16 = p16.get("gemm_bf3_kernel (linear, split-bf16 MFMA)")
-            res["bf16_mode"] = {"value": round(B * n16 / dt16, 3), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * dt16 / n16, 2),
-                                "gemm_tflops": round(g16["work"] / (g16["ms"] * 1e-3) / 1e12, 1) if g16 and g16["ms"] > 0 else None,
-                                "gemm_frac_of_bf16_peak": round(g16["work"] / (g16["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if g16 and g16["ms"] > 0 else None,
-                                "note": "A3R_GEMM=bf16 (BASELINE config 5's mode): one bf16 MFMA pass per product, fp32 accumulate -- REDUCED "
-                                        "precision (tolerances: tensor-max 5e-2, per-point p99 2e-1, ATE/extent 1e-2, rotation 6 deg; "
-                                        "tests/test_gpu_bf16_mode.py), never the default and not the headline value"}
-            del eng16
-            torch.cuda.empty_cache()
-        except Exception as ex:
-            res["bf16_mode"] = {"error": f"{type(ex).__name__}: {ex}"}
+                prev = os.environ.get("A3R_GEMM")
+                os.environ["A3R_GEMM"] = mode
+                try:
+                    eng16 = PairEngine(VITL, sd, dev)       # the arithmetic mode is read when the handle is created
+                finally:
+                    if prev is None:
+                        os.environ.pop("A3R_GEMM", None)
+                    else:
+                        os.environ["A3R_GEMM"] = prev
+                eng16.forward(*inputs[0], out=out)
+                torch.cuda.synchronize()
+                _lib.prof_enable(True)
+                t0 = time.perf_counter()
+                n16 = 2
+                for s in range(n16):
+                    eng16.forward(*inputs[s % n_batches], out=out)
+                torch.cuda.synchronize()
+                dt16 = time.perf_counter() - t0
+                _lib.prof_enable(False)
+                p16 = {p["name"]: p for p in _lib.prof_report()}
+                g16 = p16.get(kern)
+                res[key] = {"value": round(B * n16 / dt16, 3), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * dt16 / n16, 2),
+                            "gemm_tflops": round(g16["work"] / (g16["ms"] * 1e-3) / 1e12, 1) if g16 and g16["ms"] > 0 else None,
+                            "gemm_frac_of_16bit_peak": round(g16["work"] / (g16["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if g16 and g16["ms"] > 0 else None,
+                            "note": f"A3R_GEMM={mode} (BASELINE config 5's reduced-precision role): {what}, fp32 accumulate -- REDUCED "
+                                    "precision (tolerances: tensor-max 5e-2, per-point p99 2e-1, ATE/extent 1e-2, rotation 6 deg; "
+                                    "tests/test_gpu_bf16_mode.py), never the default and not the headline value"}
+                del eng16
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                res[key] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # ---- extra (not the headline): the flow provider of BASELINE config 4 -- RAFT2 ("SEA-RAFT", the network cloud_opt_flow runs for every
     # edge in both directions, optimizer.py:118-154) at the clip's resolution, 12 pairs per call and 20 iterations as the reference

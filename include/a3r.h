@@ -171,6 +171,11 @@ size_t a3r_bf3_bytes(long rows, int K);
  * effectively 16 bits (error ~2^-17 per product).  1: a0 b0 only = plain bf16 operands, fp32 accumulation -- BASELINE config 5's
  * "bf16-MFMA mode", a reduced-precision mode that is never the default.  Returns the previous value; other values are ignored. */
 int a3r_bf3_set_products(int products);
+/* Process-wide arithmetic mode of the fh2 kernels (a3r_linear_fh2 / a3r_conv3x3_fh2 / a3r_attention_fh2): matrix passes per product.
+ * 3 (default): h0 g0 + h0 g1 + h1 g0, fp32-grade.  1: h0 g0 only = plain fp16 operands (11 significant bits, kept inside fp16's range by
+ * the same per-site scales), fp32 accumulation -- the 16-bit operand mode (A3R_GEMM=f16; BASELINE config 5's reduced-precision role with
+ * three more mantissa bits than bf16), never the default.  Returns the previous value; other values are ignored. */
+int a3r_fh2_set_passes(int passes);
 /* fp32 x [M, ldx] (first K columns) -> bf3 y [M][K/8][3][8] */
 int a3r_split_bf3(const float* x, int ldx, void* y, long M, int K, void* stream);
 /* WEIGHT operands (w3 of a3r_linear_bf3, wp3 of a3r_conv3x3_bf3) use the row-pair form of the layout,

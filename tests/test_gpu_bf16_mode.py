@@ -8,7 +8,11 @@ Two levels, both on ViT-L at 512x384:
       trajectories are compared with the pose metric of tool/pose_test.py (ATE after Sim(3) alignment, restated in
       align3r_amd/tool/pose_metrics.py): ATE / trajectory extent is the acceptance number of the mode.
 The frames are synthetic noise and the weights synthetic, so the trajectory has no physical meaning; what is measured is how far
-the reduced precision moves the aligner's answer on the same problem."""
+the reduced precision moves the aligner's answer on the same problem.
+
+Round 3: the same two tests also run for A3R_GEMM=f16 -- the fh2 kernels with ONE pass per product (plain fp16 operands under the
+range control of the default path, a3r_fh2_set_passes(1)) -- against the SAME frozen bounds: three more mantissa bits than bf16, so it
+must sit inside them with room (margins are recorded), and it is the faster of the two 16-bit modes (bench extra `f16_mode`)."""
 import numpy as np
 import pytest
 import torch
@@ -33,13 +37,13 @@ def to_dev(*arrs):
     return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
 
 
-@pytest.fixture(scope="module")
-def engines():
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def engines(request):
     import os
     from align3r_amd.engine import PairEngine
     sd = synthetic_state_dict(VITL, 0)
     old = os.environ.get("A3R_GEMM")
-    os.environ["A3R_GEMM"] = "bf16"
+    os.environ["A3R_GEMM"] = request.param
     try:
         e16 = PairEngine(VITL, sd)
     finally:
@@ -48,6 +52,7 @@ def engines():
         else:
             os.environ["A3R_GEMM"] = old
     e32 = PairEngine(VITL, sd)
+    e16.mode_name = request.param
     return e32, e16
 
 
@@ -57,10 +62,10 @@ def test_bf16_mode_pair_vs_oracle(engines):
     v = make_view_arrays(2, H, W, seed=2)
     r = e16.forward(*to_dev(v[0][0], v[1][0], v[0][1], v[1][1]))
     ref = O.forward(v[0][0], v[1][0], v[0][1], v[1][1], synthetic_state_dict(VITL, 0), VITL)
-    m = pair_margins("bf16_mode_vitl_512x384_vs_oracle", {k: t.cpu().numpy() for k, t in r.items()}, ref)
+    m = pair_margins(f"{e16.mode_name}_mode_vitl_512x384_vs_oracle", {k: t.cpu().numpy() for k, t in r.items()}, ref)
     for k in ("pts3d_1", "conf_1", "pts3d_2", "conf_2"):
         assert m[f"{k}/tensor_max"] < BF16_TENSOR_MAX, (k, m[f"{k}/tensor_max"])
-        assert m[f"{k}/tensor_max"] > 1e-4, "bf16 mode must really be a different arithmetic"
+        assert m[f"{k}/tensor_max"] > 1e-4, "the 16-bit modes must really be a different arithmetic"
         assert m[f"{k}/per_elem(max,p99.9,p99,p50)"][2] < BF16_POINT_P99, (k, m[f"{k}/per_elem(max,p99.9,p99,p50)"])
 
 
@@ -92,7 +97,7 @@ def test_bf16_mode_pose_level(engines):
     c = P32[:, :3, 3]
     extent = float(np.sqrt(((c - c.mean(0)) ** 2).sum(1).mean()))
     rot = [np.degrees(np.arccos(np.clip((np.trace(P32[i, :3, :3].T @ est[i, :3, :3]) - 1) / 2, -1, 1))) for i in range(n)]
-    record_margin("bf16_mode_pose_level", ate=ate, extent=extent, ate_over_extent=ate / extent, max_rot_deg=max(rot),
+    record_margin(f"{e16.mode_name}_mode_pose_level", ate=ate, extent=extent, ate_over_extent=ate / extent, max_rot_deg=max(rot),
                   loss_f32=poses["f32"][1], loss_bf16=poses["bf16"][1],
                   pts3d_1_tensor_max=rel_err(poses["bf16"][2]["pts3d_1"], poses["f32"][2]["pts3d_1"]))
     assert ate / extent < BF16_ATE_REL, (ate, extent)

@@ -31,6 +31,8 @@ def timeit(fn, iters=10):
 
 def main():
     scale = float(os.environ.get("A3R_BENCH_MSCALE", "1"))      # 3.5 = the bench's 42 pairs per step
+    if os.environ.get("A3R_BENCH_PASSES") == "1":               # the single-pass (fp16 operand) build of the same kernel
+        ops.fh2_set_passes(1)
     global SHAPES
     SHAPES = [(n, int(M * scale) if M < 100000 else M, N, K, G, c) for n, M, N, K, G, c in SHAPES]
     tiles = sys.argv[1:] or ["auto", "0", "1"]
