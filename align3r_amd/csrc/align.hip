@@ -798,6 +798,153 @@ __global__ __launch_bounds__(TPB) void align_flow_kernel(AlignDev d, const int* 
     }
 }
 
+// The same pass for P % 4 == 0 (every model resolution), restructured like the main kernel (round 3): a thread owns FOUR CONSECUTIVE
+// pixels, so an edge side's flow is two 16-byte loads per thread, requested one edge side ahead into a second register pair; the
+// incidence codes, the partner image and its transform come by scalar loads; the 17 per-slot sums use the DPP reduce-scatter
+// (16 of them: 32 VALU + one 16-byte LDS store per quad) instead of 17 four-step butterflies with masked stores.  The first form
+// was bound by its own instruction stream (2.2 TB/s on BASELINE config 4's problem: 2.05 ms of a 3.96 ms iteration).
+__global__ __launch_bounds__(TPB, 4) void align_flow_vec_kernel(AlignDev d, const int* __restrict__ inc_ptr, const int* __restrict__ inc,
+                                                              const int* __restrict__ other, const float* __restrict__ img_xf) {
+    __shared__ float red[2][EB][16][NFP];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = d.P, W = d.fW;
+    const int p0 = chunk * CHUNK + tid * PXT;
+    const bool in = p0 < P;                                   // the four pixels are in or out together (P % 4 == 0)
+    const int kbeg = inc_ptr[n], kend = inc_ptr[n + 1];
+    auto load_flow = [&](int k, f32x4& fx, f32x4& fy) {
+        const int code = inc[__builtin_amdgcn_readfirstlane(k)];
+        const float* fl = ((code & 1) ? d.flow_ji : d.flow_ij) + (size_t)(code >> 1) * 2 * P + (in ? p0 : 0);
+        fx = *reinterpret_cast<const f32x4*>(fl);
+        fy = *reinterpret_cast<const f32x4*>(fl + P);
+    };
+    f32x4 fxa, fya, fxb, fyb;
+    f32x4 dep4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned dyn4 = 0xffffffffu;
+    if (in) {
+        dep4 = *reinterpret_cast<const f32x4*>(d.depth + (size_t)n * P + p0);
+        dyn4 = *reinterpret_cast<const unsigned*>(d.dyn + (size_t)n * P + p0);
+    }
+    if (kbeg < kend) load_flow(kbeg, fxa, fya);               // right behind the depth: the set-up arithmetic runs under its latency
+    const float* ix = img_xf + n * 16;
+    float Rs[9], Ts[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { Rs[r * 3] = ix[r * 4]; Rs[r * 3 + 1] = ix[r * 4 + 1]; Rs[r * 3 + 2] = ix[r * 4 + 2]; Ts[r] = ix[r * 4 + 3]; }
+    const float fs = ix[12], cxs = ix[13], cys = ix[14];
+    float px[PXT], py[PXT], dpv[PXT], Pw[PXT][3], g0[PXT][3], g1[PXT][3];
+    bool ok[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        const int p = p0 + i;
+        ok[i] = in && ((dyn4 >> (8 * i)) & 0xffu) == 0;        // mask = ~dynamic_mask of the source image
+        const float dp = (in ? expf(dep4[i]) : 1.f) + 1e-6f;   // 1 / disp
+        dpv[i] = dp;
+        const int y = p / W, x = p - y * W;
+        px[i] = (float)x; py[i] = (float)y;
+        const float X0 = dp * (px[i] - cxs) / fs, X1 = dp * (py[i] - cys) / fs, X2 = dp;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Pw[i][r] = Rs[r * 3] * X0 + Rs[r * 3 + 1] * X1 + Rs[r * 3 + 2] * X2 + Ts[r];
+            g0[i][r] = 0.f; g1[i][r] = 0.f;
+        }
+    }
+    auto consume = [&](int k, const f32x4& fx, const f32x4& fy, int buf, int kb) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+        const int side = inc[ku] & 1, t = other[ku];
+        const float* tx = img_xf + t * 16;
+        const float r00 = tx[0], r01 = tx[1], r02 = tx[2], t0 = tx[3];
+        const float r10 = tx[4], r11 = tx[5], r12 = tx[6], t1 = tx[7];
+        const float r20 = tx[8], r21 = tx[9], r22 = tx[10], t2 = tx[11];
+        const float ft = tx[12], cxt = tx[13], cyt = tx[14];
+        float acc[NF];
+#pragma unroll
+        for (int j = 0; j < NF; j++) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const float gt0 = ok[i] ? fx[i] : 0.f, gt1 = ok[i] ? fy[i] : 0.f;
+            const float v0 = Pw[i][0] - t0, v1 = Pw[i][1] - t1, v2 = Pw[i][2] - t2;
+            const float Y0 = r00 * v0 + r10 * v1 + r20 * v2;        // Y = R_t^T v
+            const float Y1 = r01 * v0 + r11 * v1 + r21 * v2;
+            const float Y2 = r02 * v0 + r12 * v1 + r22 * v2;
+            const float qx = ft * Y0 + cxt * Y2, qy = ft * Y1 + cyt * Y2;
+            const float den = Y2 + 1e-6f * dpv[i];
+#ifdef A3R_FLOW_IEEE_DIV
+            const float iz = 1.f / den;
+#else
+            // v_rcp_f32 (1 ulp) + one Newton step instead of the IEEE division's expansion (a dozen instructions per pixel side)
+            const float r0 = __builtin_amdgcn_rcpf(den);
+            const float iz = r0 * (2.f - den * r0);
+#endif
+            const float e0 = qx * iz - px[i], e1 = qy * iz - py[i];
+            float gn0 = 0.f, gn1 = 0.f;
+            if (ok[i]) {
+                const float d0 = e0 - gt0, a0 = fabsf(d0), l0 = a0 < 1.f ? 0.5f * d0 * d0 : a0 - 0.5f;
+                const float d1 = e1 - gt1, a1 = fabsf(d1), l1 = a1 < 1.f ? 0.5f * d1 * d1 : a1 - 0.5f;
+                if (l0 < d.pxl_thre) { acc[0] += l0; acc[1] += 1.f; gn0 = a0 < 1.f ? d0 : (d0 > 0.f ? 1.f : -1.f); }
+                if (l1 < d.pxl_thre) { acc[0] += l1; acc[1] += 1.f; gn1 = a1 < 1.f ? d1 : (d1 > 0.f ? 1.f : -1.f); }
+            }
+            const float gq0 = gn0 * iz, gq1 = gn1 * iz, gq2 = -(gn0 * qx + gn1 * qy) * iz * iz;
+            const float gY0 = ft * gq0, gY1 = ft * gq1, gY2 = cxt * gq0 + cyt * gq1 + gq2;
+            acc[2] += gq0 * Y0 + gq1 * Y1;
+            acc[3] += gq0 * Y2;
+            acc[4] += gq1 * Y2;
+            acc[5] += gY0; acc[6] += gY1; acc[7] += gY2;
+            acc[8] += v0 * gY0; acc[9] += v0 * gY1; acc[10] += v0 * gY2;
+            acc[11] += v1 * gY0; acc[12] += v1 * gY1; acc[13] += v1 * gY2;
+            acc[14] += v2 * gY0; acc[15] += v2 * gY1; acc[16] += v2 * gY2;
+            const float gw0 = r00 * gY0 + r01 * gY1 + r02 * gY2;     // gPw = R_t gY
+            const float gw1 = r10 * gY0 + r11 * gY1 + r12 * gY2;
+            const float gw2 = r20 * gY0 + r21 * gY1 + r22 * gY2;
+            // (side is wave-uniform: a select per component instead of a branch around the adds)
+            g0[i][0] += side ? 0.f : gw0; g0[i][1] += side ? 0.f : gw1; g0[i][2] += side ? 0.f : gw2;
+            g1[i][0] += side ? gw0 : 0.f; g1[i][1] += side ? gw1 : 0.f; g1[i][2] += side ? gw2 : 0.f;
+        }
+        float v16[16], u[4];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v16[j] = acc[j];
+        row_reduce_scatter16<16>(v16, u);
+        const float s16 = dpp_row_sum16(acc[16]);
+        float* row = &red[buf][kb][wave * 4 + (lane >> 4)][0];
+        if ((lane & 3) == 0) *reinterpret_cast<f32x4*>(row + (lane & 12)) = f32x4{u[0], u[1], u[2], u[3]};
+        if ((lane & 15) == 0) row[16] = s16;
+    };
+    int buf = 0, kb = 0, k0 = kbeg;
+#pragma unroll 1
+    for (int k = kbeg; k < kend; k += 2) {
+        const bool has1 = k + 1 < kend;
+        if (has1) load_flow(k + 1, fxb, fyb);
+        consume(k, fxa, fya, buf, kb);
+        if (has1) {
+            if (k + 2 < kend) load_flow(k + 2, fxa, fya);
+            consume(k + 1, fxb, fyb, buf, kb + 1);
+        }
+        kb += 2;
+        if (kb == EB || k + 2 >= kend) {
+            __syncthreads();
+            for (int idx = tid; idx < EB * NFP; idx += TPB) {
+                const int sb = idx / NFP, j = idx - sb * NFP, ks = k0 + sb;
+                if (ks < kend && j < NF) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) s += red[buf][sb][r][j];
+                    d.partF[((size_t)ks * d.nchunks + chunk) * NFP + j] = s;
+                }
+            }
+            buf ^= 1; kb = 0; k0 += EB;
+        }
+    }
+    if (in) {
+        const size_t NP3 = (size_t)d.N * P * 3;
+        f32x4* o = reinterpret_cast<f32x4*>(d.gflow + ((size_t)n * P + p0) * 3);
+        f32x4* o1 = reinterpret_cast<f32x4*>(d.gflow + NP3 + ((size_t)n * P + p0) * 3);
+        o[0] = f32x4{g0[0][0], g0[0][1], g0[0][2], g0[1][0]};
+        o[1] = f32x4{g0[1][1], g0[1][2], g0[2][0], g0[2][1]};
+        o[2] = f32x4{g0[2][2], g0[3][0], g0[3][1], g0[3][2]};
+        o1[0] = f32x4{g1[0][0], g1[0][1], g1[0][2], g1[1][0]};
+        o1[1] = f32x4{g1[1][1], g1[1][2], g1[2][0], g1[2][1]};
+        o1[2] = f32x4{g1[2][2], g1[3][0], g1[3][1], g1[3][2]};
+    }
+}
+
 // grid 2E x 64 threads: fixed-order sum of the chunk partials of one incidence slot
 __global__ __launch_bounds__(64) void align_flow_reduce_kernel(AlignDev d) {
     const int k = blockIdx.x, lane = threadIdx.x;
@@ -1387,7 +1534,11 @@ static void launch_flow(a3r_align_s* a, int epoch, hipStream_t st) {
     d.flow_on = (d.flow_w > 0.f && epoch >= a->flow_start_iter) ? 1 : 0;
     if (!d.flow_on) return;
     ProfScope prof(PK_ALIGN_SMALL, 0.0, st);
-    hipLaunchKernelGGL(align_flow_kernel, dim3(d.nchunks, d.N), dim3(TPB), 0, st, d, d.inc_ptr, d.inc, d.other, d.img_xf);
+    static const bool flow_v1 = getenv("A3R_ALIGN_FLOW") && std::string(getenv("A3R_ALIGN_FLOW")) == "v1";    // A/B switch: the first form
+    const bool vec = d.P % 4 == 0 && !flow_v1 && ((reinterpret_cast<uintptr_t>(d.flow_ij) | reinterpret_cast<uintptr_t>(d.flow_ji) |
+                                                   reinterpret_cast<uintptr_t>(d.gflow) | reinterpret_cast<uintptr_t>(d.dyn)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(align_flow_vec_kernel, dim3(d.nchunks, d.N), dim3(TPB), 0, st, d, d.inc_ptr, d.inc, d.other, d.img_xf);
+    else hipLaunchKernelGGL(align_flow_kernel, dim3(d.nchunks, d.N), dim3(TPB), 0, st, d, d.inc_ptr, d.inc, d.other, d.img_xf);
     hipLaunchKernelGGL(align_flow_reduce_kernel, dim3(2 * d.E), dim3(64), 0, st, d);
     hipLaunchKernelGGL(align_flow_decide_kernel, dim3(1), dim3(TPB), 0, st, d, d.inc);
 }

@@ -494,6 +494,50 @@ def main():
             except Exception as ex:
                 res["align_config3"] = {"error": f"{type(ex).__name__}: {ex}"}
 
+        # ---- extra: the flow aligner at BASELINE config 4's FULL size on one GPU (128 frames 384 x 512, swinstride-5 graph symmetrised:
+        # E = 1230; ego-flow term on synthetic flow fields, temporal smoothing, shared focal); parity: tests/test_gpu_align.py
+        if not a.no_align_config3 and world == 1:
+            try:
+                torch.cuda.empty_cache()
+                N4, H4, W4 = 128, 384, 512
+                prs = make_pairs([dict(idx=i) for i in range(N4)], "swinstride-5-noncyclic", symmetrize=True)
+                e4 = [(p[0]["idx"], p[1]["idx"]) for p in prs]
+                E4, P4 = len(e4), H4 * W4
+                gd = torch.Generator(device=dev).manual_seed(4)
+                rn = lambda *sh: torch.randn(*sh, generator=gd, device=dev)
+                fl = dict(flow_ij=2 * rn(E4, 2, P4), flow_ji=2 * rn(E4, 2, P4), dyn=torch.zeros(N4, P4, dtype=torch.bool), weight=0.01, thre=1e9,
+                          start_epoch=0.0, num_total_iter=43, pxl_thre=1e9)
+                al4 = AlignEngine([i for i, j in e4], [j for i, j in e4], rn(E4, P4, 3), rn(E4, P4, 3),
+                                  torch.log(1 + 9 * torch.rand(E4, P4, generator=gd, device=dev)),
+                                  torch.log(1 + 9 * torch.rand(E4, P4, generator=gd, device=dev)), [(H4, W4)] * N4, device=dev, loss_capacity=128,
+                                  shared_focal=True, temporal_smoothing_weight=0.01, translation_weight=1.0, flow=fl)
+                pw4, im4 = 0.05 * rn(E4, 8), 0.05 * rn(N4, 7)
+                pw4[:, 3] += 1.0
+                im4[:, 3] += 1.0
+                al4.set_params(pw_poses=pw4, depth=0.1 * rn(N4, P4), im_poses=im4, im_focals=torch.full((N4,), 20 * float(np.log(max(H4, W4)))))
+                al4.run(3, 0.01, "linear", total_iters=43)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                al4.run(20, 0.01, "linear", first_iter=3, total_iters=43)
+                torch.cuda.synchronize()
+                dt4 = time.perf_counter() - t0
+                _lib.prof_enable(True)
+                al4.run(20, 0.01, "linear", first_iter=23, total_iters=43)
+                torch.cuda.synchronize()
+                _lib.prof_enable(False)
+                rep4 = {p["name"]: p for p in _lib.prof_report()}
+                p4 = rep4["align_main_kernel"]
+                res["align_config4"] = {"iters_per_s": round(20 / dt4, 2), "N": N4, "E": E4, "P": P4, "flow_term": not al4.flow_dropped,
+                                        "main_kernel_us": round(1e3 * p4["ms"] / max(p4["launches"], 1), 1),
+                                        "main_kernel_gbs": round(p4["work"] / (p4["ms"] * 1e-3) / 1e9, 1),
+                                        "kernels_us_per_iter": {k: round(1e3 * v["ms"] / 20, 1) for k, v in rep4.items() if k.startswith("align")},
+                                        "note": "BASELINE config 4's alignment problem on ONE GPU: 3-D term + ego-flow term (synthetic flow fields) + temporal "
+                                                "smoothing + shared focal; its 2460 flow fields cost 2460 / raft_flow.value seconds once per clip"}
+                del al4, fl
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                res["align_config4"] = {"error": f"{type(ex).__name__}: {ex}"}
+
     # ---- CPU baseline: the oracle on this box's host cores (rank 0, N=1 only, bounded sample)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import model_np

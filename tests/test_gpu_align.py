@@ -204,6 +204,59 @@ def test_config3_full_size_vs_oracle(Engine):
     assert all(v < 1e-5 for k, v in margins.items() if k.startswith("state_") and k != "state_pw_poses"), margins
 
 
+def test_config4_full_size_vs_oracle(Engine):
+    """BASELINE config 4's alignment problem at FULL size on one GPU -- 128 frames of 384 x 512, swinstride-5 window graph symmetrised
+    (E = 1230 edges, 7.7 GB of pair observations + 3.9 GB of optical flow) with cloud_opt_flow's terms switched on: ego-flow loss
+    against synthetic flow fields (N(0, 2 px), all-false dynamic masks, never dropped), temporal smoothing, one shared focal --
+    against oracle/align_ref.c: loss and every gradient of the first evaluation with the flow term on (1e-6 / 1e-5), then 2 Adam
+    steps.  Near-identity cameras and unit depths, so that the ego-flow is a few pixels; state bounds as in the config-3 test."""
+    from conftest import record_margin
+    from oracle.align_ref import AlignOracle
+    from align3r_amd.dust3r.image_pairs import make_pairs
+    N, H, W = 128, 384, 512
+    pairs = make_pairs([dict(idx=i) for i in range(N)], "swinstride-5-noncyclic", symmetrize=True)
+    edges = [(a["idx"], b["idx"]) for a, b in pairs]
+    E, P = len(edges), H * W
+    assert E == 1230
+    rng = np.random.default_rng(44)
+    p1 = rng.standard_normal((E, P, 3), dtype=np.float32)
+    p2 = rng.standard_normal((E, P, 3), dtype=np.float32)
+    w1 = np.log1p(9 * rng.random((E, P), dtype=np.float32))
+    w2 = np.log1p(9 * rng.random((E, P), dtype=np.float32))
+    flow = dict(flow_ij=2 * rng.standard_normal((E, 2, P), dtype=np.float32), flow_ji=2 * rng.standard_normal((E, 2, P), dtype=np.float32),
+                dyn=np.zeros((N, P), bool), weight=0.01, thre=1e9, start_epoch=0.0, num_total_iter=50, pxl_thre=1e9)
+    unit = lambda n, k: (0.05 * rng.standard_normal((n, k))).astype(np.float32)
+    pw, im = unit(E, 8), unit(N, 7)
+    pw[:, 3] += 1.0
+    im[:, 3] += 1.0                                              # quaternions near identity
+    init = dict(pw_poses=pw, depth=(0.1 * rng.standard_normal((N, P))).astype(np.float32), im_poses=im,
+                im_focals=np.full(N, 20 * np.log(max(H, W)), np.float32))
+    args = ([i for i, j in edges], [j for i, j in edges], p1, p2, w1, w2, [(H, W)] * N)
+    kw = dict(shared_focal=True, temporal_smoothing_weight=0.01, translation_weight=1.0, flow=flow)
+    o = AlignOracle(*args, **kw)
+    a = Engine(*args, **kw)
+    for eng in (o, a):
+        eng.set_params(**init)
+    lo, go = o.loss_grad(9999)
+    la, ga = a.loss_grad(9999)
+    margins = dict(loss0=abs(lo - la) / lo)
+    for k in go:
+        margins[f"grad_{k}"] = rel_err(host(ga[k]).reshape(go[k].shape), go[k])
+    lo = np.asarray(o.run(2, 0.01, "linear", total_iters=50))
+    la = a.run(2, 0.01, "linear", total_iters=50)
+    margins["losses"] = rel_err(la, lo)
+    for k in o.trainable():
+        margins[f"state_{k}"] = rel_err(host(a.params[k]).reshape(o.params[k].shape), o.params[k])
+    record_margin("align_config4_full_size_vs_oracle", **margins)
+    assert not a.flow_dropped and not o.flow_dropped
+    del o, a, p1, p2, w1, w2, flow
+    assert margins["loss0"] < 1e-6, margins
+    assert all(v < 1e-5 for k, v in margins.items() if k.startswith("grad_")), margins
+    assert margins["losses"] < 1e-5, margins
+    assert all(v < 1e-3 for k, v in margins.items() if k.startswith("state_")), margins
+    assert all(v < 1e-5 for k, v in margins.items() if k.startswith("state_") and k != "state_pw_poses"), margins
+
+
 def test_fused_tail_is_bitwise_the_launch_path(Engine, monkeypatch):
     """A3R_ALIGN_TAIL=fused finishes the iteration inside the main launch (two levels of last-block-done tickets, write-through
     partial rows, agent-scope acquire) instead of the two finalize launches.  Same sums in the same order: losses and every

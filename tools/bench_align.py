@@ -44,7 +44,9 @@ def run(N, H, W, graph, mono, iters=100, flow=False):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
-    if which == "one":
+    if which == "c4":
+        run(128, 384, 512, "swinstride-5-noncyclic", False, iters=20, flow=True)
+    elif which == "one":
         run(16, 384, 512, "swin-3-noncyclic", False)
     elif which == "small":
         run(16, 384, 512, "swin-3-noncyclic", False)
