@@ -855,7 +855,7 @@ __global__ __launch_bounds__(TPB, 4) void align_flow_vec_kernel(AlignDev d, cons
         const float r10 = tx[4], r11 = tx[5], r12 = tx[6], t1 = tx[7];
         const float r20 = tx[8], r21 = tx[9], r22 = tx[10], t2 = tx[11];
         const float ft = tx[12], cxt = tx[13], cyt = tx[14];
-        float acc[NF];
+        float acc[NF], gw[PXT][3];
 #pragma unroll
         for (int j = 0; j < NF; j++) acc[j] = 0.f;
 #pragma unroll
@@ -891,12 +891,16 @@ __global__ __launch_bounds__(TPB, 4) void align_flow_vec_kernel(AlignDev d, cons
             acc[8] += v0 * gY0; acc[9] += v0 * gY1; acc[10] += v0 * gY2;
             acc[11] += v1 * gY0; acc[12] += v1 * gY1; acc[13] += v1 * gY2;
             acc[14] += v2 * gY0; acc[15] += v2 * gY1; acc[16] += v2 * gY2;
-            const float gw0 = r00 * gY0 + r01 * gY1 + r02 * gY2;     // gPw = R_t gY
-            const float gw1 = r10 * gY0 + r11 * gY1 + r12 * gY2;
-            const float gw2 = r20 * gY0 + r21 * gY1 + r22 * gY2;
-            // (side is wave-uniform: a select per component instead of a branch around the adds)
-            g0[i][0] += side ? 0.f : gw0; g0[i][1] += side ? 0.f : gw1; g0[i][2] += side ? 0.f : gw2;
-            g1[i][0] += side ? gw0 : 0.f; g1[i][1] += side ? gw1 : 0.f; g1[i][2] += side ? gw2 : 0.f;
+            gw[i][0] = r00 * gY0 + r01 * gY1 + r02 * gY2;            // gPw = R_t gY
+            gw[i][1] = r10 * gY0 + r11 * gY1 + r12 * gY2;
+            gw[i][2] = r20 * gY0 + r21 * gY1 + r22 * gY2;
+        }
+        if (side) {                                                  // wave-uniform (a scalar load): a scalar branch, no selects
+#pragma unroll
+            for (int i = 0; i < PXT; i++) { g1[i][0] += gw[i][0]; g1[i][1] += gw[i][1]; g1[i][2] += gw[i][2]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PXT; i++) { g0[i][0] += gw[i][0]; g0[i][1] += gw[i][1]; g0[i][2] += gw[i][2]; }
         }
         float v16[16], u[4];
 #pragma unroll
