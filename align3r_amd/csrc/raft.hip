@@ -546,8 +546,11 @@ void resnet(RPlan& P, const std::string& p, float* s, int nimg, int H2, int W2, 
 // RAFT2.forward(test_mode=True) (raft.py:185-246) for B pairs.  img1 / img2 [B, 3, H, W] with values in [0, 255]; flow_out [B, 2, H, W]
 // (the last prediction; the reference up-samples every iteration's flow and returns the list, its caller keeps `[1]`).
 // taps: optional intermediate copies for the parity tests (any pointer may be null).
+// phase 0: the whole forward (fmap1_in / fmap2_in given: the feature network is skipped and those per-frame features are used);
+// phase 1: the feature network alone on B frames `img1` -> fmap_out [B, h, w, 2 dim] (a3r_raft_encode)
 int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int B, int H, int W, int iters, float* flow_out, void* ws,
-              size_t ws_bytes, void* stream, size_t* peak, const a3r_raft_taps* taps) {
+              size_t ws_bytes, void* stream, size_t* peak, const a3r_raft_taps* taps, int phase = 0, const float* fmap1_in = nullptr,
+              const float* fmap2_in = nullptr, float* fmap_out = nullptr) {
     const a3r_raft_config& c = m->cfg;
     const int d = c.dim, h = H / 8, w = W / 8, H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1;
     const long hw = (long)h * w, Bhw = (long)B * hw;
@@ -560,6 +563,19 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         if (dry || P.rc || !dst) return;
         if (hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) { set_error("a3r_raft_forward: tap copy failed"); P.rc = A3R_EHIP; }
     };
+    if (phase == 1) {
+        // the feature network on B frames: fnet(2 x / 255 - 1) (raft.py:222-223); its rows do not depend on what else is in the batch
+        float* s = ar.alloc((size_t)B * H2 * W2 * c.initial_dim);
+        P.launch([&](hipStream_t st) {
+            DirectConvArgs a = {img1, nullptr, 3, 0, 3L * H * W, (long)H * W, W, 1, B, H, W, 7, 2, 3, H2, W2, c.initial_dim, 2.f / 255.f, -1.f,
+                                P.auxw("fnet.conv1.weight"), P.wptr("fnet.conv1.bias"), 1, s};
+            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * ((W2 + DC_PX - 1) / DC_PX) * c.initial_dim)), dim3(256), 0, st, a);
+        });
+        float* fo = dry ? ar.alloc(Bhw * 2 * d) : fmap_out;
+        resnet(P, "fnet", s, B, H2, W2, fo, nullptr, 2 * d);
+        if (peak) *peak = ar.peak;
+        return P.rc;
+    }
     // ---------------- persistent buffers
     float* cn = ar.alloc(Bhw * 2 * d);                  // init_conv output: [net | context]
     float* fm3 = ar.alloc3(2 * Bhw, 2 * d);             // fnet(image1), fnet(image2) in bf3 form (rows: all of image1, then image2)
@@ -594,7 +610,15 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
     P.pack_cols(net, d, 0, cn, 2 * d, d, Bhw);
     P.pack_cols(X, 3 * d, d, cn + d, 2 * d, d, Bhw);
     // ---------------- feature network on both images (raft.py:222-223) and the correlation pyramid (corr.py:11-23)
-    {
+    if (fmap1_in && fmap2_in) {                                      // per-frame features computed once by a3r_raft_encode
+        if (!P.skip()) {
+            const size_t bytes = (size_t)Bhw * 2 * d * 4;
+            if (hipMemcpyAsync(fm, fmap1_in, bytes, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess ||
+                hipMemcpyAsync(fm + (size_t)Bhw * 2 * d, fmap2_in, bytes, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) {
+                set_error("a3r_raft_forward_features: copy failed"); P.rc = A3R_EHIP;
+            }
+        }
+    } else {
         float* s = ar.alloc((size_t)2 * B * H2 * W2 * c.initial_dim);
         for (int k = 0; k < 2; k++)
             P.launch([&](hipStream_t st) {
@@ -747,6 +771,29 @@ extern "C" size_t a3r_raft_workspace_bytes(a3r_raft_t m, int B, int H, int W) {
     size_t peak = 0;
     raft_plan(m, true, nullptr, nullptr, B, H, W, 1, nullptr, nullptr, 0, nullptr, &peak, nullptr);
     return peak;
+}
+
+extern "C" int a3r_raft_encode(a3r_raft_t m, const float* image, int B, int H, int W, float* fmap, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (int rc = raft_check(m, B, H, W, 0, "a3r_raft_encode")) return rc;
+    if (!m->finalized) { set_error("a3r_raft_encode: a3r_raft_finalize has not been called"); return A3R_ESTATE; }
+    A3R_CHECK_ARG(image && fmap && workspace, "a3r_raft_encode: null pointer");
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "a3r_raft_encode: workspace must be 256-byte aligned");
+    size_t need_bytes = 0;
+    raft_plan(m, true, nullptr, nullptr, B, H, W, 0, nullptr, nullptr, 0, nullptr, &need_bytes, nullptr, 1);
+    A3R_CHECK_ARG(workspace_bytes >= need_bytes, "a3r_raft_encode: workspace too small (%zu < %zu)", workspace_bytes, need_bytes);
+    return raft_plan(m, false, image, nullptr, B, H, W, 0, nullptr, workspace, workspace_bytes, stream, nullptr, nullptr, 1, nullptr, nullptr, fmap);
+}
+
+extern "C" int a3r_raft_forward_features(a3r_raft_t m, const float* image1, const float* image2, const float* fmap1, const float* fmap2, int B,
+                                         int H, int W, int iters, float* flow, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = raft_check(m, B, H, W, iters, "a3r_raft_forward_features")) return rc;
+    if (!m->finalized) { set_error("a3r_raft_forward_features: a3r_raft_finalize has not been called"); return A3R_ESTATE; }
+    A3R_CHECK_ARG(image1 && image2 && fmap1 && fmap2 && flow && workspace, "a3r_raft_forward_features: null pointer");
+    A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "a3r_raft_forward_features: workspace must be 256-byte aligned");
+    const size_t need_bytes = a3r_raft_workspace_bytes(m, B, H, W);
+    A3R_CHECK_ARG(workspace_bytes >= need_bytes, "a3r_raft_forward_features: workspace too small (%zu < %zu)", workspace_bytes, need_bytes);
+    return raft_plan(m, false, image1, image2, B, H, W, iters, flow, workspace, workspace_bytes, stream, nullptr, nullptr, 0, fmap1, fmap2);
 }
 
 extern "C" int a3r_raft_forward(a3r_raft_t m, const float* image1, const float* image2, int B, int H, int W, int iters, float* flow,

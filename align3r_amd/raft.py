@@ -77,10 +77,49 @@ class RaftEngine:
         except Exception:
             pass
 
-    def forward(self, image1, image2, iters=20, taps=None):
+    def _workspace(self, B, H, W):
+        need = int(self.lib.a3r_raft_workspace_bytes(self.handle, B, H, W))
+        if need == 0:
+            raise RuntimeError(f"RAFT: image size {H}x{W} must be a multiple of 8")
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.workspace
+
+    def encode(self, image):
+        """The feature network alone (a3r_raft_encode): image [B, 3, H, W] in [0, 255] -> fmap [B, H/8, W/8, 2 dim].  A frame's features
+        do not depend on its partner; forward(..., fmaps=(fmap1, fmap2)) then skips the feature network."""
+        B, _, H, W = image.shape
+        if tuple(image.shape) != (B, 3, H, W) or image.dtype != torch.float32 or not image.is_contiguous() or image.device != self.device:
+            raise RuntimeError(f"image: expected contiguous float32 {(B, 3, H, W)} on {self.device}")
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B, H, W)
+            fmap = torch.empty((B, H // 8, W // 8, 2 * self.cfg.dim), device=self.device, dtype=torch.float32)
+            check(self.lib.a3r_raft_encode(self.handle, ptr(image), B, H, W, ptr(fmap), ptr(ws), ws.numel(), stream_ptr()), "a3r_raft_encode")
+        return fmap
+
+    def forward(self, image1, image2, iters=20, taps=None, fmaps=None):
         """image* [B, 3, H, W] in [0, 255] (device fp32) -> flow [B, 2, H, W].  taps: dict name -> preallocated device tensor
-        (parity tests): cnet, fmap, corr_pyr0..3, flow_update0, weight0, lookup0, motion0, net0..3, flow8_0..3."""
+        (parity tests): cnet, fmap, corr_pyr0..3, flow_update0, weight0, lookup0, motion0, net0..3, flow8_0..3.
+        fmaps: (fmap1, fmap2) from encode() of the two frame batches."""
         B, _, H, W = image1.shape
+        if fmaps is not None:
+            f1, f2 = fmaps
+            shp = (B, H // 8, W // 8, 2 * self.cfg.dim)
+            for t, nm in ((image1, "image1"), (image2, "image2")):
+                if tuple(t.shape) != (B, 3, H, W) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                    raise RuntimeError(f"{nm}: expected contiguous float32 {(B, 3, H, W)} on {self.device}")
+            for t, nm in ((f1, "fmap1"), (f2, "fmap2")):
+                if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                    raise RuntimeError(f"{nm}: expected contiguous float32 {shp} on {self.device}")
+            if taps:
+                raise RuntimeError("taps are only available without fmaps")
+            with torch.cuda.device(self.device):
+                ws = self._workspace(B, H, W)
+                flow = torch.empty((B, 2, H, W), device=self.device, dtype=torch.float32)
+                check(self.lib.a3r_raft_forward_features(self.handle, ptr(image1), ptr(image2), ptr(f1), ptr(f2), B, H, W, int(iters), ptr(flow),
+                                                         ptr(ws), ws.numel(), stream_ptr()), "a3r_raft_forward_features")
+            return flow
         for t, nm in ((image1, "image1"), (image2, "image2")):
             if tuple(t.shape) != (B, 3, H, W) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
                 raise RuntimeError(f"{nm}: expected contiguous float32 {(B, 3, H, W)} on {self.device}, got {tuple(t.shape)} {t.dtype} {t.device}")

@@ -468,6 +468,14 @@ size_t a3r_raft_workspace_bytes(a3r_raft_t m, int B, int H, int W);
  * 16 << (corr_levels - 1) (its pyramid needs it, corr.py:22). */
 int a3r_raft_forward(a3r_raft_t m, const float* image1, const float* image2, int B, int H, int W, int iters, float* flow,
                      void* workspace, size_t workspace_bytes, const a3r_raft_taps* taps, void* stream);
+/* The feature network alone: fmap [B, H/8, W/8, 2 dim] = fnet(2 image / 255 - 1) for B frames (raft.py:222-223).  A frame's features do
+ * not depend on the pair it appears in: the reference's cloud_opt_flow re-encodes every frame for every edge and direction
+ * (optimizer.py:141-146); computing them once per frame and passing them to a3r_raft_forward_features gives the same flow with a
+ * third fewer FLOPs.  workspace: a3r_raft_workspace_bytes(m, B, H, W) is sufficient. */
+int a3r_raft_encode(a3r_raft_t m, const float* image, int B, int H, int W, float* fmap, void* workspace, size_t workspace_bytes, void* stream);
+/* a3r_raft_forward with the two feature maps given (fmap1 / fmap2 [B, H/8, W/8, 2 dim] from a3r_raft_encode of image1 / image2). */
+int a3r_raft_forward_features(a3r_raft_t m, const float* image1, const float* image2, const float* fmap1, const float* fmap2, int B, int H,
+                              int W, int iters, float* flow, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (4) global alignment inner loop: PointCloudOptimizer (cloud_opt/optimizer.py, base_opt.py)

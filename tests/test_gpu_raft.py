@@ -92,6 +92,26 @@ def test_raft_m_as_the_reference_calls_it(g, tag, H, W, seed):
     assert e20 < TOL, e20
 
 
+def test_raft_per_frame_feature_cache_is_bitwise_the_full_forward():
+    """a3r_raft_encode + a3r_raft_forward_features against a3r_raft_forward: a frame's feature map does not depend on the batch it was
+    encoded in nor on its partner, so the flow from cached per-frame features equals the full forward's bit for bit (what
+    cloud_opt_flow.get_flow relies on when it encodes every frame once)."""
+    from align3r_amd.raft import RaftEngine
+    eng = RaftEngine(RAFT_TINY, synthetic_raft_state_dict(RAFT_TINY, 0))
+    i1, i2 = synthetic_raft_frames(3, 128, 160, 17)
+    frames = dev(np.concatenate([i1, i2]))                         # six frames
+    fm_all = eng.encode(frames)                                    # one batch of six
+    fm_one = torch.cat([eng.encode(frames[k:k + 1].contiguous()) for k in range(6)])
+    assert torch.equal(fm_all, fm_one)                             # batch-invariant
+    full = eng.forward(frames[:3].contiguous(), frames[3:].contiguous(), iters=4)
+    cached = eng.forward(frames[:3].contiguous(), frames[3:].contiguous(), iters=4, fmaps=(fm_all[:3].contiguous(), fm_all[3:].contiguous()))
+    assert torch.equal(full, cached)
+    back = eng.forward(frames[3:].contiguous(), frames[:3].contiguous(), iters=4, fmaps=(fm_all[3:].contiguous(), fm_all[:3].contiguous()))
+    assert torch.equal(back, eng.forward(frames[3:].contiguous(), frames[:3].contiguous(), iters=4))
+    with pytest.raises(RuntimeError, match="fmap1"):
+        eng.forward(frames[:3].contiguous(), frames[3:].contiguous(), fmaps=(fm_all[:2].contiguous(), fm_all[3:].contiguous()))
+
+
 def test_raft_errors_are_loud():
     from align3r_amd.raft import RAFT2, RaftEngine
     sd = synthetic_raft_state_dict(RAFT_TINY, 0)
