@@ -97,9 +97,12 @@ class PointCloudOptimizer(_Base):
             # calls take the two maps as inputs: the same flow fields (asserted bitwise in tests/test_gpu_raft.py), a third fewer FLOPs.
             frames = (torch.from_numpy(imgs).float().permute(0, 3, 1, 2).contiguous() * 255).to(eng.device)
             fmaps = torch.cat([eng.encode(frames[s0:s0 + 12].contiguous()) for s0 in range(0, len(frames), 12)])
-            for s0 in range(0, len(self.edges), 12):                                        # chunk_size = 12 (optimizer.py:135)
-                ii = torch.as_tensor(ei[s0:s0 + 12], device=eng.device)
-                jj = torch.as_tensor(ej[s0:s0 + 12], device=eng.device)
+            # chunk_size = 12 in the reference (optimizer.py:135) is a memory choice of its GPU; a pair's flow does not depend on the
+            # batch it is computed in (bitwise, tests/test_gpu_raft.py), and 48 pairs per call fill this chip better (+12 %)
+            chunk = max(1, int(os.environ.get('A3R_RAFT_CHUNK', '48')))
+            for s0 in range(0, len(self.edges), chunk):
+                ii = torch.as_tensor(ei[s0:s0 + chunk], device=eng.device)
+                jj = torch.as_tensor(ej[s0:s0 + chunk], device=eng.device)
                 a, b, fa, fb = frames[ii], frames[jj], fmaps[ii], fmaps[jj]
                 f_ij.append(eng.forward(a, b, iters=20, fmaps=(fa, fb)))
                 f_ji.append(eng.forward(b, a, iters=20, fmaps=(fb, fa)))

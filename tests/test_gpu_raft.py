@@ -108,6 +108,8 @@ def test_raft_per_frame_feature_cache_is_bitwise_the_full_forward():
     assert torch.equal(full, cached)
     back = eng.forward(frames[3:].contiguous(), frames[:3].contiguous(), iters=4, fmaps=(fm_all[3:].contiguous(), fm_all[:3].contiguous()))
     assert torch.equal(back, eng.forward(frames[3:].contiguous(), frames[:3].contiguous(), iters=4))
+    one = eng.forward(frames[1:2].contiguous(), frames[4:5].contiguous(), iters=4, fmaps=(fm_all[1:2].contiguous(), fm_all[4:5].contiguous()))
+    assert torch.equal(one, cached[1:2])                           # a pair's flow does not depend on the batch it is computed in
     with pytest.raises(RuntimeError, match="fmap1"):
         eng.forward(frames[:3].contiguous(), frames[3:].contiguous(), fmaps=(fm_all[:2].contiguous(), fm_all[3:].contiguous()))
 

@@ -18,4 +18,13 @@ for _ in range(3):
     eng.forward(a, b, iters=iters)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
-print(f"B={B} iters={iters}: {1e3 * dt:.1f} ms per call, {B / dt:.1f} fields/s")
+print(f"B={B} iters={iters}: {1e3 * dt:.1f} ms per call, {B / dt:.1f} fields/s", flush=True)
+fa, fb = eng.encode(a), eng.encode(b)
+eng.forward(a, b, iters=iters, fmaps=(fa, fb))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    eng.forward(a, b, iters=iters, fmaps=(fa, fb))
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+print(f"B={B} iters={iters} cached frame features: {1e3 * dt:.1f} ms per call, {B / dt:.1f} fields/s", flush=True)
