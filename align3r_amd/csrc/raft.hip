@@ -17,6 +17,7 @@
 // Maps are channels-last fp32 [B, h, w, C]; all buffers live in the caller's workspace.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <new>
 #include <string>
@@ -74,6 +75,56 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < DC_PX; q++)
+            if (ox0 + q < a.Wo) a.y[(((long)b * a.Ho + oy) * a.Wo + ox0 + q) * a.Cout + co] = a.relu ? fmaxf(acc[q], 0.f) : acc[q];
+    }
+}
+
+// The same convolution with the filter size, stride and pixels per thread fixed at compile time (the 7x7 stems, stride 2, and the
+// update block's convf1, stride 1): per (channel, filter row) a thread loads the (PX - 1) S + K input columns its PX outputs share
+// ONCE (normalised on the way in, zeros outside the image -- fma(0, w, acc) = acc, so the sums are bitwise those of the generic
+// kernel, which skips the taps) and then runs K x PX fused multiply-adds from registers; the generic form issued one bounds-checked
+// load per multiply-add.  Lanes are consecutive output channels: the input loads are broadcasts, the weight loads coalesced.
+template <int K, int S, int PX>
+__global__ __launch_bounds__(256) void direct_conv_fixed_kernel(DirectConvArgs a) {
+    constexpr int NI = (PX - 1) * S + K;
+    const int WoG = (a.Wo + PX - 1) / PX;
+    const long total = (long)a.B * a.Ho * WoG * a.Cout;
+    const int Cin = a.c0 + a.c1;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int co = (int)(i % a.Cout);
+        long p = i / a.Cout;
+        const int ox0 = (int)(p % WoG) * PX; p /= WoG;
+        const int oy = (int)(p % a.Ho);
+        const int b = (int)(p / a.Ho);
+        float acc[PX];
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int q = 0; q < PX; q++) acc[q] = bias;
+        const int ix0 = ox0 * S - a.pad;
+        for (int c = 0; c < Cin; c++) {
+            const float* src = (c < a.c0 ? a.x0 + (long)c * a.sc : a.x1 + (long)(c - a.c0) * a.sc) + (long)b * a.sb;
+#pragma unroll 1
+            for (int ky = 0; ky < K; ky++) {
+                const int iy = oy * S - a.pad + ky;
+                if (iy < 0 || iy >= a.H) continue;
+                const float* row = src + (long)iy * a.sy;
+                float in[NI];
+#pragma unroll
+                for (int t = 0; t < NI; t++) {
+                    const int ix = ix0 + t;
+                    in[t] = (ix >= 0 && ix < a.W) ? row[(long)ix * a.sx] * a.in_mul + a.in_add : 0.f;
+                }
+                const float* wr = a.w + (size_t)((c * K + ky) * K) * a.Cout + co;
+#pragma unroll
+                for (int kx = 0; kx < K; kx++) {
+                    const float wv = wr[(size_t)kx * a.Cout];
+#pragma unroll
+                    for (int q = 0; q < PX; q++) acc[q] = __fmaf_rn(in[q * S + kx], wv, acc[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PX; q++)
             if (ox0 + q < a.Wo) a.y[(((long)b * a.Ho + oy) * a.Wo + ox0 + q) * a.Cout + co] = a.relu ? fmaxf(acc[q], 0.f) : acc[q];
     }
 }
@@ -247,6 +298,16 @@ __global__ void transpose_kernel(const float* __restrict__ w, float* __restrict_
 static inline unsigned grid1d(long n) {
     const long b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : b > 65536 ? 65536 : b);
+}
+
+// 7x7 convolutions of 2..6 input channels (stems, convf1): the fixed-size kernel where it applies, the generic one otherwise
+static void launch_direct_conv(const DirectConvArgs& a, hipStream_t st) {
+    constexpr int PX = 8;
+    const long work = (long)a.B * a.Ho * ((a.Wo + PX - 1) / PX) * a.Cout;
+    static const bool generic = getenv("A3R_RAFT_DIRECT_CONV") && std::string(getenv("A3R_RAFT_DIRECT_CONV")) == "generic";     // A/B switch
+    if (!generic && a.k == 7 && a.stride == 2) hipLaunchKernelGGL((direct_conv_fixed_kernel<7, 2, PX>), dim3(grid1d(work)), dim3(256), 0, st, a);
+    else if (!generic && a.k == 7 && a.stride == 1) hipLaunchKernelGGL((direct_conv_fixed_kernel<7, 1, PX>), dim3(grid1d(work)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)a.B * a.Ho * ((a.Wo + DC_PX - 1) / DC_PX) * a.Cout)), dim3(256), 0, st, a);
 }
 
 struct RWRef { const float* p = nullptr; std::vector<int64_t> shape; };
@@ -569,7 +630,7 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         P.launch([&](hipStream_t st) {
             DirectConvArgs a = {img1, nullptr, 3, 0, 3L * H * W, (long)H * W, W, 1, B, H, W, 7, 2, 3, H2, W2, c.initial_dim, 2.f / 255.f, -1.f,
                                 P.auxw("fnet.conv1.weight"), P.wptr("fnet.conv1.bias"), 1, s};
-            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * ((W2 + DC_PX - 1) / DC_PX) * c.initial_dim)), dim3(256), 0, st, a);
+            launch_direct_conv(a, st);
         });
         float* fo = dry ? ar.alloc(Bhw * 2 * d) : fmap_out;
         resnet(P, "fnet", s, B, H2, W2, fo, nullptr, 2 * d);
@@ -598,7 +659,7 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         P.launch([&](hipStream_t st) {
             DirectConvArgs a = {img1, img2, 3, 3, 3L * H * W, (long)H * W, W, 1, B, H, W, 7, 2, 3, H2, W2, c.initial_dim, 2.f / 255.f, -1.f,
                                 P.auxw("cnet.conv1.weight"), P.wptr("cnet.conv1.bias"), 1, s};
-            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * ((W2 + DC_PX - 1) / DC_PX) * c.initial_dim)), dim3(256), 0, st, a);
+            launch_direct_conv(a, st);
         });
         float* c3 = ar.alloc3(Bhw, 2 * d);
         resnet(P, "cnet", s, B, H2, W2, nullptr, c3, 2 * d);
@@ -624,7 +685,7 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
             P.launch([&](hipStream_t st) {
                 DirectConvArgs a = {k ? img2 : img1, nullptr, 3, 0, 3L * H * W, (long)H * W, W, 1, B, H, W, 7, 2, 3, H2, W2, c.initial_dim, 2.f / 255.f, -1.f,
                                     P.auxw("fnet.conv1.weight"), P.wptr("fnet.conv1.bias"), 1, s + (size_t)k * B * H2 * W2 * c.initial_dim};
-                hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * H2 * ((W2 + DC_PX - 1) / DC_PX) * c.initial_dim)), dim3(256), 0, st, a);
+                launch_direct_conv(a, st);
             });
         resnet(P, "fnet", s, 2 * B, H2, W2, fm, nullptr, 2 * d);
     }
@@ -712,7 +773,7 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
         P.launch([&](hipStream_t st) {                                                                      // flo = relu(convf1(flow)): 7x7 on 2 channels
             DirectConvArgs a = {flow8, nullptr, 2, 0, hw * 2, 1, (long)w * 2, 2, B, h, w, 7, 1, 3, h, w, d, 1.f, 0.f,
                                 P.auxw(enc + "convf1.weight"), P.wptr(enc + "convf1.bias"), 1, f1};
-            hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1d((long)B * h * ((w + DC_PX - 1) / DC_PX) * d)), dim3(256), 0, st, a);
+            launch_direct_conv(a, st);
         });
         P.split(f1, d, f13, Bhw, d);
         P.conv3(f13, enc + "convf2", tmp, B, h, w, d, d / 2, 1, P.epi(A3R_EPI_RELU, nullptr));              // flo = relu(convf2(flo))
