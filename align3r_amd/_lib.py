@@ -158,6 +158,8 @@ SIGNATURES = {
     "a3r_raft_packed_bytes": (C.c_size_t, [c_void]),
     "a3r_raft_finalize": (C.c_int, [c_void, c_void, C.c_size_t, c_void]),
     "a3r_raft_workspace_bytes": (C.c_size_t, [c_void, C.c_int, C.c_int, C.c_int]),
+    "a3r_raft_set_arith": (C.c_int, [c_void, C.c_int]),
+    "a3r_raft_range": (C.c_int, [c_void, C.POINTER(C.c_float), c_void]),
     "a3r_raft_encode": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, c_void]),
     "a3r_raft_forward_features": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, c_void]),
     "a3r_raft_forward": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_size_t, C.POINTER(RaftTaps), c_void]),

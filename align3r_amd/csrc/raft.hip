@@ -8,6 +8,8 @@
 //   CorrBlock2 (pyramid over down-sampled fmap2)       corr.py:10-60, utils/utils.py:76-91 (bilinear_sampler)
 //   BasicUpdateBlock2 / BasicMotionEncoder2            update.py:99-174
 //   ConvNextBlock / LayerNorm                          layer.py:35-104
+// Round 3: the default arithmetic is the two-plane fp16 form (fh2 kernels, a3r_raft_set_arith(1)); the three-plane bf16 form below
+// stays as the fp32-range fallback (a3r_raft_set_arith(0)) that RaftEngine re-runs when a3r_raft_range reports a value outside fp16.
 // Every 3x3 convolution and every 1x1 / Linear runs on the exact three-plane bf16 matrix-core kernels (gemm_bf3.hip: fp32-accurate, fp32
 // range -- the flow network is a few per cent of a clip's work, so it takes the form that needs no range control); the all-pairs
 // correlation is that GEMM with the second feature map as the weight operand.  What has no GEMM shape is here: the 7x7 stems on 3 / 6 /
@@ -321,15 +323,19 @@ struct a3r_raft_s {
     bool finalized = false;
     std::map<std::string, const void*> twin;        // conv / linear weight name -> bf3 twin in the packed buffer (weight layout)
     std::map<std::string, const float*> aux;        // depthwise weights transposed
+    // the same weights in fh2 form (two fp16 planes of scale * w) with their power-of-two scales: the default arithmetic (round 3)
+    std::map<std::string, std::pair<const void*, float>> twin2;
+    bool use_fh2 = true;                            // a3r_raft_set_arith
+    unsigned* stat = nullptr;                       // device word: max |value written in fh2 form| of the last forward (range check)
 };
 
 // ------------------------------------------------------------------------------------------- weight plan
 namespace {
-struct RItem { std::string name; int kind; int N, K; size_t off, tmp; };      // kind 0: conv3x3 [N, K/9 ch]; 1: linear [N, K]; 2: depthwise [C=N]; 3: direct conv [N, K = Cin 49], transposed
+struct RItem { std::string name; int kind; int N, K; size_t off, tmp; size_t off2 = 0; };      // kind 0: conv3x3 [N, K/9 ch]; 1: linear [N, K]; 2: depthwise [C=N]; 3: direct conv [N, K = Cin 49], transposed
 
 void resnet_convs(const std::string& p, const a3r_raft_config& c, std::vector<RItem>* v, int output_dim, size_t* off) {
     auto add = [&](const std::string& n, int kind, int N, int K) {
-        RItem it{n, kind, N, K, *off, 0};
+        RItem it{n, kind, N, K, *off, 0, 0};
         *off = align_up(*off + a3r_bf3_w_bytes(N, K), 256);
         if (kind == 0) { it.tmp = *off; *off = align_up(*off + (size_t)N * K * 4, 256); }      // fp32 [Cout, 3, 3, Cin] staging
         v->push_back(it);
@@ -354,7 +360,7 @@ std::vector<RItem> raft_pack_plan(const a3r_raft_config& c, size_t* total) {
     size_t off = 0;
     const int d = c.dim;
     auto add = [&](const std::string& n, int kind, int N, int K) {
-        RItem it{n, kind, N, K, off, 0};
+        RItem it{n, kind, N, K, off, 0, 0};
         if (kind == 2) { off = align_up(off + (size_t)N * 49 * 4, 256); v.push_back(it); return; }
         if (kind == 3) { off = align_up(off + (size_t)N * K * 4, 256); v.push_back(it); return; }      // direct-conv weight, transposed
         off = align_up(off + a3r_bf3_w_bytes(N, K), 256);
@@ -384,6 +390,11 @@ std::vector<RItem> raft_pack_plan(const a3r_raft_config& c, size_t* total) {
         add(q + "pwconv2.weight", 1, 3 * d, 4 * d);
         add(q + "final.weight", 1, d, 3 * d);
     }
+    // second image of every conv / linear weight: fh2 form (4 bytes per element); then one line for the range statistic and the
+    // absmax scratch word of the packing pass
+    for (RItem& it : v)
+        if (it.kind == 0 || it.kind == 1) { it.off2 = off; off = align_up(off + (size_t)it.N * it.K * 4, 256); }
+    off = align_up(off + 256, 256);
     *total = off;
     return v;
 }
@@ -399,6 +410,22 @@ int rneed(a3r_raft_s* m, const std::string& name, std::vector<int64_t> shape, co
         return A3R_EINVAL;
     }
     *out = it->second.p;
+    return A3R_OK;
+}
+
+// fh2 image of one weight ([N, K] fp32 at src) with its power-of-two scale (max |w| into [2^12, 2^13))
+int pack_fh2(a3r_raft_s* m, const RItem& it, const float* src, char* pk, size_t total, void* stream) {
+    float* scratch = reinterpret_cast<float*>(pk + total - 128);
+    if (int rc = a3r_absmax(src, (long)it.N * it.K, scratch, stream)) return rc;
+    float amax = 0.f;
+    if (hipMemcpyAsync(&amax, scratch, 4, hipMemcpyDeviceToHost, as_stream(stream)) != hipSuccess || hipStreamSynchronize(as_stream(stream)) != hipSuccess) {
+        set_error("a3r_raft_finalize: reading the weight range failed");
+        return A3R_EHIP;
+    }
+    A3R_CHECK_ARG(std::isfinite(amax), "a3r_raft_finalize: weight '%s' is not finite", it.name.c_str());
+    const float scale = a3r_fh2_weight_scale(amax);
+    if (int rc = a3r_split_fh2(src, it.K, pk + it.off2, it.N, it.K, scale, nullptr, stream)) return rc;
+    m->twin2[it.name] = {pk + it.off2, scale};
     return A3R_OK;
 }
 }  // namespace
@@ -448,7 +475,9 @@ extern "C" int a3r_raft_finalize(a3r_raft_t m, void* packed, size_t packed_bytes
     A3R_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 255) == 0, "a3r_raft_finalize: packed buffer must be 256-byte aligned");
     char* pk = static_cast<char*>(packed);
     m->twin.clear();
+    m->twin2.clear();
     m->aux.clear();
+    m->stat = reinterpret_cast<unsigned*>(pk + total - 256);
     for (const RItem& it : plan) {
         const float* src;
         if (it.kind == 0) {
@@ -458,6 +487,7 @@ extern "C" int a3r_raft_finalize(a3r_raft_t m, void* packed, size_t packed_bytes
             if (int rc = a3r_pack_conv3x3(src, tmp, it.N, cin, stream)) return rc;
             if (int rc = a3r_split_bf3_w(tmp, it.K, pk + it.off, it.N, it.K, stream)) return rc;
             m->twin[it.name] = pk + it.off;
+            if (int rc = pack_fh2(m, it, tmp, pk, total, stream)) return rc;
         } else if (it.kind == 1) {
             // Linear weights are [N, K]; 1x1 convolutions [N, K, 1, 1]
             auto wi = m->w.find(it.name);
@@ -467,6 +497,7 @@ extern "C" int a3r_raft_finalize(a3r_raft_t m, void* packed, size_t packed_bytes
             A3R_CHECK_ARG(ok, "a3r_raft_finalize: weight '%s' must be [%d, %d] (or [%d, %d, 1, 1])", it.name.c_str(), it.N, it.K, it.N, it.K);
             if (int rc = a3r_split_bf3_w(wi->second.p, it.K, pk + it.off, it.N, it.K, stream)) return rc;
             m->twin[it.name] = pk + it.off;
+            if (int rc = pack_fh2(m, it, wi->second.p, pk, total, stream)) return rc;
         } else if (it.kind == 3) {
             if (int rc = rneed(m, it.name, {it.N, it.K / 49, 7, 7}, &src)) return rc;
             float* wt = reinterpret_cast<float*>(pk + it.off);
@@ -524,22 +555,49 @@ struct RPlan {
         e.epi = kind; e.bias = bias; e.resid = resid;
         return e;
     }
-    // 3x3 convolution `name` (weight / bias) on the bf3 map x3 [B, H, W, Cin]
+    // The plan below is written for the three-plane bf16 form ("x3" operands, out_bf3 / aux_bf3 epilogues).  With m->use_fh2 the
+    // same calls run on the fh2 kernels (3 fp16 passes instead of 6 bf16 ones, 4 instead of 6 operand bytes): operands are fh2
+    // matrices with scale 1 (they fit the buffers sized for bf3), out_bf3 / aux_bf3 mean out_fh2 / aux_fh2, and every fh2 producer
+    // reports max |stored value| into m->stat, which the caller checks against fp16's range after the forward.
+    bool fh2() const { return m->use_fh2; }
+    std::pair<const void*, float> twin2(const std::string& n) {
+        auto it = m->twin2.find(n);
+        if (it == m->twin2.end()) { if (!rc) { set_error("a3r_raft_forward: weight '%s' was not packed", n.c_str()); rc = A3R_ESTATE; } return {nullptr, 1.f}; }
+        return it->second;
+    }
+    void to_fh2(a3r_epilogue& e) {
+        e.out_fh2 = e.out_bf3; e.out_bf3 = 0;
+        e.aux_fh2 = e.aux_bf3; e.aux_bf3 = nullptr;
+        e.out_absmax = (e.out_fh2 || e.aux_fh2) ? m->stat : nullptr;
+    }
+    // 3x3 convolution `name` (weight / bias) on the bf3 / fh2 map x3 [B, H, W, Cin]
     void conv3(const float* x3, const std::string& name, float* y, int B, int H, int W, int Cin, int Cout, int stride, a3r_epilogue e) {
         if (skip()) return;
         e.bias = wptr(name + ".bias");
+        if (fh2()) {
+            const auto w2 = twin2(name + ".weight");
+            to_fh2(e);
+            if (!rc) rc = a3r_conv3x3_fh2(x3, w2.first, w2.second, y, B, H, W, Cin, Cout, stride, &e, stream);
+            return;
+        }
         const void* w3 = twin(name + ".weight");
         if (!rc) rc = a3r_conv3x3_bf3(x3, w3, y, B, H, W, Cin, Cout, stride, &e, stream);
     }
     void linear(const float* x3, const std::string& name, float* y, int ldc, long M, int N, int K, a3r_epilogue e) {
         if (skip()) return;
         e.bias = wptr(name + ".bias");
+        if (fh2()) {
+            const auto w2 = twin2(name + ".weight");
+            to_fh2(e);
+            if (!rc) rc = a3r_linear_fh2(x3, w2.first, w2.second, y, ldc, (int)M, N, K, &e, stream);
+            return;
+        }
         const void* w3 = twin(name + ".weight");
         if (!rc) rc = a3r_linear_bf3(x3, w3, y, ldc, (int)M, N, K, &e, stream);
     }
     void split(const float* x, int ldx, float* y3, long M, int K) {
         if (skip()) return;
-        rc = a3r_split_bf3(x, ldx, y3, M, K, stream);
+        rc = fh2() ? a3r_split_fh2(x, ldx, y3, M, K, 1.f, m->stat, stream) : a3r_split_bf3(x, ldx, y3, M, K, stream);
     }
     template <class F> void launch(F&& f) {
         if (skip()) return;
@@ -620,6 +678,10 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
     P.m = m; P.stream = stream;
     P.ar = {static_cast<char*>(ws), 0, ws_bytes, dry, 0};
     RArena& ar = P.ar;
+    if (!dry && m->use_fh2 && m->stat && hipMemsetAsync(m->stat, 0, 4, as_stream(stream)) != hipSuccess) {
+        set_error("a3r_raft_forward: clearing the range statistic failed");
+        return A3R_EHIP;
+    }
     auto tap = [&](float* dst, const float* src, size_t n) {
         if (dry || P.rc || !dst) return;
         if (hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, as_stream(stream)) != hipSuccess) { set_error("a3r_raft_forward: tap copy failed"); P.rc = A3R_EHIP; }
@@ -708,8 +770,13 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
             const long n2 = (long)hl[l] * wl[l];
             for (int b = 0; b < B; b++) {
                 if (P.skip()) break;
-                P.rc = a3r_split_bf3_w(f2 + (size_t)b * n2 * D, D, w3, n2, D, stream);
                 a3r_epilogue e = {};
+                if (P.fh2()) {
+                    P.rc = a3r_split_fh2(f2 + (size_t)b * n2 * D, D, w3, n2, D, 1.f, m->stat, stream);
+                    if (!P.rc) P.rc = a3r_linear_fh2(reinterpret_cast<char*>(fm3) + (size_t)b * hw * D * 4, w3, 1.f, corr[l] + (size_t)b * hw * n2, (int)n2, (int)hw, (int)n2, D, &e, stream);
+                    continue;
+                }
+                P.rc = a3r_split_bf3_w(f2 + (size_t)b * n2 * D, D, w3, n2, D, stream);
                 if (!P.rc) P.rc = a3r_linear_bf3(reinterpret_cast<char*>(fm3) + (size_t)b * hw * D * 6, w3, corr[l] + (size_t)b * hw * n2, (int)n2, (int)hw, (int)n2, D, &e, stream);
             }
             if (l + 1 < c.corr_levels) {                             // fmap2 <- interpolate(fmap2, 0.5) (corr.py:22)
@@ -794,7 +861,9 @@ int raft_plan(a3r_raft_s* m, bool dry, const float* img1, const float* img2, int
                 auto wi = P.m->aux.find(q + "dwconv.weight");
                 hipLaunchKernelGGL(dwconv7_kernel, dim3(grid1d((long)B * h * ((w + 3) / 4) * 3 * d)), dim3(256), 0, st, X, wi->second, P.wptr(q + "dwconv.bias"), dw, B, h, w, 3 * d);
             });
-            if (!P.skip()) P.rc = a3r_layernorm_bf3(dw, P.wptr(q + "norm.weight"), P.wptr(q + "norm.bias"), ln3, (int)Bhw, 3 * d, 1e-6f, 0, stream);
+            if (!P.skip())
+                P.rc = P.fh2() ? a3r_layernorm_fh2(dw, P.wptr(q + "norm.weight"), P.wptr(q + "norm.bias"), ln3, (int)Bhw, 3 * d, 1e-6f, 1.f, m->stat, stream)
+                               : a3r_layernorm_bf3(dw, P.wptr(q + "norm.weight"), P.wptr(q + "norm.bias"), ln3, (int)Bhw, 3 * d, 1e-6f, 0, stream);
             a3r_epilogue eg = P.epi(A3R_EPI_GELU, nullptr);
             eg.out_bf3 = 1;
             P.linear(ln3, q + "pwconv1", hid3, 4 * d, Bhw, 4 * d, 3 * d, eg);
@@ -832,6 +901,21 @@ extern "C" size_t a3r_raft_workspace_bytes(a3r_raft_t m, int B, int H, int W) {
     size_t peak = 0;
     raft_plan(m, true, nullptr, nullptr, B, H, W, 1, nullptr, nullptr, 0, nullptr, &peak, nullptr);
     return peak;
+}
+
+extern "C" int a3r_raft_set_arith(a3r_raft_t m, int fh2) {
+    A3R_CHECK_ARG(m, "a3r_raft_set_arith: null handle");
+    const int prev = m->use_fh2 ? 1 : 0;
+    m->use_fh2 = fh2 != 0;
+    return prev;
+}
+
+extern "C" int a3r_raft_range(a3r_raft_t m, float* max_abs_host, void* stream) {
+    A3R_CHECK_ARG(m && max_abs_host, "a3r_raft_range: null argument");
+    if (!m->finalized || !m->stat) { set_error("a3r_raft_range: a3r_raft_finalize has not been called"); return A3R_ESTATE; }
+    A3R_HIP(hipMemcpyAsync(max_abs_host, m->stat, 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    A3R_HIP(hipStreamSynchronize(as_stream(stream)));
+    return A3R_OK;
 }
 
 extern "C" int a3r_raft_encode(a3r_raft_t m, const float* image, int B, int H, int W, float* fmap, void* workspace, size_t workspace_bytes,

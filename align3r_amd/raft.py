@@ -68,6 +68,28 @@ class RaftEngine:
             check(self.lib.a3r_raft_finalize(self.handle, ptr(self.packed), nbytes, stream_ptr()), "a3r_raft_finalize")
             torch.cuda.current_stream().synchronize()
         self.workspace = None
+        # arithmetic: the two-plane fp16 form unless A3R_RAFT=bf3; a call whose activations leave fp16's range is repeated on bf3
+        import os
+        self.fh2 = os.environ.get("A3R_RAFT", "fh2") != "bf3"
+        self.range_fallbacks = 0
+        self.lib.a3r_raft_set_arith(self.handle, 1 if self.fh2 else 0)
+
+    def _ranged(self, launch):
+        """Run `launch` (which enqueues one call and returns its output); in fh2 arithmetic read the call's range statistic and, if a
+        stored activation reached 2^15 (fp16 tops out at 65504; NaN counts), repeat the call on the three-plane bf16 kernels."""
+        out = launch()
+        if not self.fh2:
+            return out
+        mx = C.c_float(0.0)
+        check(self.lib.a3r_raft_range(self.handle, C.byref(mx), stream_ptr()), "a3r_raft_range")
+        if mx.value < 32768.0:                                   # (a NaN fails this comparison)
+            return out
+        self.range_fallbacks += 1
+        self.lib.a3r_raft_set_arith(self.handle, 0)
+        try:
+            return launch()
+        finally:
+            self.lib.a3r_raft_set_arith(self.handle, 1)
 
     def __del__(self):
         try:
@@ -95,8 +117,11 @@ class RaftEngine:
         with torch.cuda.device(self.device):
             ws = self._workspace(B, H, W)
             fmap = torch.empty((B, H // 8, W // 8, 2 * self.cfg.dim), device=self.device, dtype=torch.float32)
-            check(self.lib.a3r_raft_encode(self.handle, ptr(image), B, H, W, ptr(fmap), ptr(ws), ws.numel(), stream_ptr()), "a3r_raft_encode")
-        return fmap
+
+            def launch():
+                check(self.lib.a3r_raft_encode(self.handle, ptr(image), B, H, W, ptr(fmap), ptr(ws), ws.numel(), stream_ptr()), "a3r_raft_encode")
+                return fmap
+            return self._ranged(launch)
 
     def forward(self, image1, image2, iters=20, taps=None, fmaps=None):
         """image* [B, 3, H, W] in [0, 255] (device fp32) -> flow [B, 2, H, W].  taps: dict name -> preallocated device tensor
@@ -117,9 +142,12 @@ class RaftEngine:
             with torch.cuda.device(self.device):
                 ws = self._workspace(B, H, W)
                 flow = torch.empty((B, 2, H, W), device=self.device, dtype=torch.float32)
-                check(self.lib.a3r_raft_forward_features(self.handle, ptr(image1), ptr(image2), ptr(f1), ptr(f2), B, H, W, int(iters), ptr(flow),
-                                                         ptr(ws), ws.numel(), stream_ptr()), "a3r_raft_forward_features")
-            return flow
+
+                def launch():
+                    check(self.lib.a3r_raft_forward_features(self.handle, ptr(image1), ptr(image2), ptr(f1), ptr(f2), B, H, W, int(iters), ptr(flow),
+                                                             ptr(ws), ws.numel(), stream_ptr()), "a3r_raft_forward_features")
+                    return flow
+                return self._ranged(launch)
         for t, nm in ((image1, "image1"), (image2, "image2")):
             if tuple(t.shape) != (B, 3, H, W) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
                 raise RuntimeError(f"{nm}: expected contiguous float32 {(B, 3, H, W)} on {self.device}, got {tuple(t.shape)} {t.dtype} {t.device}")
@@ -141,9 +169,12 @@ class RaftEngine:
                         tp.flow8[int(k[6:])] = t.data_ptr()
                     else:
                         setattr(tp, k, t.data_ptr())
-            check(self.lib.a3r_raft_forward(self.handle, ptr(image1), ptr(image2), B, H, W, int(iters), ptr(flow), ptr(self.workspace),
-                                            self.workspace.numel(), C.byref(tp) if tp is not None else None, stream_ptr()), "a3r_raft_forward")
-        return flow
+
+            def launch():
+                check(self.lib.a3r_raft_forward(self.handle, ptr(image1), ptr(image2), B, H, W, int(iters), ptr(flow), ptr(self.workspace),
+                                                self.workspace.numel(), C.byref(tp) if tp is not None else None, stream_ptr()), "a3r_raft_forward")
+                return flow
+            return self._ranged(launch)
 
 
 class RAFT2:

@@ -468,6 +468,13 @@ size_t a3r_raft_workspace_bytes(a3r_raft_t m, int B, int H, int W);
  * 16 << (corr_levels - 1) (its pyramid needs it, corr.py:22). */
 int a3r_raft_forward(a3r_raft_t m, const float* image1, const float* image2, int B, int H, int W, int iters, float* flow,
                      void* workspace, size_t workspace_bytes, const a3r_raft_taps* taps, void* stream);
+/* Arithmetic of the flow network's convolutions / linear layers / correlation: 1 (default) = the two-plane fp16 form (fh2 kernels: three
+ * fp16 MFMA passes, operands stored with scale 1), 0 = the three-plane bf16 form (six passes, fp32 range).  The fh2 form is fp32-grade
+ * while every stored activation stays inside fp16's range; every fh2 producer of a call reports max |stored value| into one device
+ * word that a3r_raft_range reads back (it waits for the stream): a caller that finds it at or above 2^15 (or NaN) repeats the call
+ * after a3r_raft_set_arith(m, 0) -- align3r_amd.raft.RaftEngine does.  set_arith returns the previous setting. */
+int a3r_raft_set_arith(a3r_raft_t m, int fh2);
+int a3r_raft_range(a3r_raft_t m, float* max_abs_host, void* stream);
 /* The feature network alone: fmap [B, H/8, W/8, 2 dim] = fnet(2 image / 255 - 1) for B frames (raft.py:222-223).  A frame's features do
  * not depend on the pair it appears in: the reference's cloud_opt_flow re-encodes every frame for every edge and direction
  * (optimizer.py:141-146); computing them once per frame and passing them to a3r_raft_forward_features gives the same flow with a

@@ -1,4 +1,5 @@
-"""GPU: RAFT2 / SEA-RAFT optical flow (csrc/raft.hip through the C ABI a3r_raft_*) against goldens produced by the
+"""GPU: RAFT2 / SEA-RAFT optical flow (csrc/raft.hip through the C ABI a3r_raft_*; default arithmetic since round 3: the
+two-plane fp16 kernels, with the three-plane bf16 ones as the range fallback) against goldens produced by the
 reference's own third_party/RAFT modules in the build container with the build's synthetic weights (tests/golden/raft.npz,
 tests/golden/make_goldens.py --only raft; inputs are rebuilt here by align3r_amd.raft_weights.synthetic_raft_frames).
 
@@ -112,6 +113,28 @@ def test_raft_per_frame_feature_cache_is_bitwise_the_full_forward():
     assert torch.equal(one, cached[1:2])                           # a pair's flow does not depend on the batch it is computed in
     with pytest.raises(RuntimeError, match="fmap1"):
         eng.forward(frames[:3].contiguous(), frames[3:].contiguous(), fmaps=(fm_all[:2].contiguous(), fm_all[3:].contiguous()))
+
+
+def test_raft_fp16_range_fallback(monkeypatch):
+    """The default arithmetic stores activations as two fp16 planes with scale 1: a call whose activations reach 2^15 is detected by
+    the range statistic (a3r_raft_range) and repeated on the three-plane bf16 kernels -- the result is bitwise that of an engine
+    created with A3R_RAFT=bf3, never a silently saturated one.  Ordinary weights do not trigger it."""
+    from align3r_amd.raft import RaftEngine
+    sd = synthetic_raft_state_dict(RAFT_TINY, 0)
+    i1, i2 = synthetic_raft_frames(1, 128, 160, 5)
+    ok = RaftEngine(RAFT_TINY, sd)
+    ok.forward(dev(i1), dev(i2), iters=2)
+    assert ok.fh2 and ok.range_fallbacks == 0
+    big = dict(sd)
+    big["cnet.layer1.0.conv1.weight"] = sd["cnet.layer1.0.conv1.weight"] * np.float32(3e5)      # context features far beyond 65504
+    e2 = RaftEngine(RAFT_TINY, big)
+    out = e2.forward(dev(i1), dev(i2), iters=2)
+    assert e2.range_fallbacks == 1
+    monkeypatch.setenv("A3R_RAFT", "bf3")
+    e3 = RaftEngine(RAFT_TINY, big)
+    assert not e3.fh2
+    ref = e3.forward(dev(i1), dev(i2), iters=2)
+    assert torch.isfinite(ref).all() and torch.equal(out, ref)
 
 
 def test_raft_errors_are_loud():
