@@ -416,13 +416,14 @@ def main():
             torch.cuda.synchronize()
             dte = (time.perf_counter() - t0) / nr
             res["raft_flow"] = {"value": round(12 / dtr, 2), "unit": "flow fields/s", "ms_per_call": round(1e3 * dtr, 2), "pairs_per_call": 12,
-                                "iters": 20, "resolution": [H, W],
+                                "iters": 20, "resolution": [H, W], "arithmetic": "fh2" if reng.fh2 else "bf3", "range_fallbacks": reng.range_fallbacks,
                                 "with_cached_frame_features": {"value": round(12 / dtc, 2), "ms_per_call": round(1e3 * dtc, 2),
                                                                "encode_ms_per_frame": round(1e3 * dte / 12, 3),
                                                                "note": "per-frame feature maps computed once (bitwise the same flow, tests/test_gpu_raft.py): "
                                                                        "how cloud_opt_flow.get_flow runs; config 4: 2460 fields + 128 frame encodings"},
                                 "note": "RAFT2 forward (both encoders, 4-level correlation pyramid, 20 update iterations, convex up-sampling) on the "
-                                        "three-plane bf16 kernels; config 4 needs 2 fields per edge (1230 edges at 128 frames, swinstride-5)"}
+                                        "two-plane fp16 kernels (range-checked, bf16 fallback); config 4 needs 2 fields per edge (1230 edges at 128 "
+                                        "frames, swinstride-5)"}
             del fma, fmb
             del reng, fa, fb
             torch.cuda.empty_cache()
