@@ -530,8 +530,10 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     g.direct_epilogue = 0;
     static const int gm_env = getenv("A3R_FH2_GM") ? atoi(getenv("A3R_FH2_GM")) : 0;
     int t = choose_fh2_tile(g.M, g.N, g.groups);
-    if ((AMODE == 1 || g.epi.epi == A3R_EPI_HEAD) && t != 0) t = 2;
-    if (g_fh2_passes == 1) t = 2;   // the implicit conv and the HEAD epilogue are built for tiles 0 and 2
+    if (g.epi.epi == A3R_EPI_HEAD && t != 0) t = 2;   // the HEAD epilogue is built for tiles 0 and 2
+    if (AMODE == 1 && t == 3) t = 2;                  // (tile 3 is a linear-only lab tile; the 128x64 tile serves convolutions with
+                                                      // 64 or 192 output channels -- the flow network's -- without a half-empty tile)
+    if (g_fh2_passes == 1) t = 2;
     const int bm = kFh2Tiles[t].bm, bn = kFh2Tiles[t].bn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -554,9 +556,8 @@ static int launch_fh2(Fh2Args& fa, hipStream_t st) {
     if (t == 2) return full ? launch_fh2_variant<128, 128, 2, 4, 2, true, AMODE>(fa, st) : launch_fh2_variant<128, 128, 2, 4, 2, false, AMODE>(fa, st);
     if constexpr (AMODE == 0) {
         if (t == 3) return full ? launch_fh2_variant<256, 128, 4, 2, 3, true>(fa, st) : launch_fh2_variant<256, 128, 4, 2, 3, false>(fa, st);
-        return full ? launch_fh2_variant<128, 64, 4, 2, 3, true>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false>(fa, st);
     }
-    return A3R_EINVAL;
+    return full ? launch_fh2_variant<128, 64, 4, 2, 3, true, AMODE>(fa, st) : launch_fh2_variant<128, 64, 4, 2, 3, false, AMODE>(fa, st);
 }
 
 // operand / output scales of one problem: 0 means 1; they must be finite and positive (powers of two by contract: only then is
