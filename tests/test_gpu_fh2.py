@@ -142,6 +142,37 @@ def test_attention_fh2_forms_are_bitwise_equal(ops, B, H, Nq, Nk):
     assert outs[0][1] == outs[1][1] and outs[0][1] > 0
 
 
+def test_single_pass_mode_is_plain_fp16_operands(ops):
+    """a3r_fh2_set_passes(1) (the 16-bit operand mode, A3R_GEMM=f16): the GEMM, the 3x3 conv and the attention evaluate h0 g0 alone, i.e.
+    they equal float64 arithmetic on the operands ROUNDED TO fp16 (first planes) up to fp32 accumulation error -- and differ from the
+    three-pass result at the 2^-11 level.  The setting is restored afterwards."""
+    M, N, K = 300, 256, 512
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
+    x2, w2 = ops.split_fh2(x), ops.split_fh2_w(w)
+    x16 = x2.planes()[0].double() / x2.scale                      # the first plane: rn_f16(scale x) / scale
+    w16 = w2.planes()[0].double() / w2.scale
+    full = ops.linear_fh2_grouped([x2], [w2], [b])[0].double()
+    prev = ops.fh2_set_passes(1)
+    try:
+        assert prev == 3
+        one = ops.linear_fh2_grouped([x2], [w2], [b])[0].double()
+        B, H, Nq = 2, 2, 100
+        q = ops.split_fh2(rnd(B * Nq, 3 * H * 64, seed=4))
+        a1 = ops.attention_fh2(q, q, q, B, H, Nq, Nq, q_col=0, k_col=H * 64, v_col=2 * H * 64).value()
+    finally:
+        assert ops.fh2_set_passes(prev) == 1
+    ref16 = x16 @ w16.T + b.double()
+    ref = x.double() @ w.double().T + b.double()
+    s = ref.abs().max()
+    assert float((one - ref16).abs().max() / s) < 2e-6            # exactly the fp16-operand product
+    e = float((one - ref).abs().max() / s)
+    assert 5e-5 < e < 3e-3, e                                      # ... which is a reduced-precision answer
+    assert float((full - ref).abs().max() / s) < 2e-6
+    a3 = ops.attention_fh2(q, q, q, B, H, Nq, Nq, q_col=0, k_col=H * 64, v_col=2 * H * 64).value()
+    ea = float((a1 - a3).abs().max() / a3.abs().max())
+    assert 1e-5 < ea < 1e-2, ea
+
+
 def test_linear_fh2_rope_to_fh2(ops):
     """The q / k projection epilogue: RoPE-2D on the leading columns, written in fh2 form, against the fp32-output epilogue of the same
     kernel and against the exact-fp32 MFMA GEMM's."""
