@@ -22,7 +22,9 @@ def classify(name):
     n = name.replace("a3r::", "").replace("void ", "")
     if "gemm_fh2_kernel<" in n:
         args = n[n.index("<") + 1:n.index(">")].split(",")
-        return "gemm_fh2_kernel<1>" if args[-1].strip() == "1" else "gemm_fh2_kernel"
+        # template <BM, BN, WM, WN, NS, FULL, AMODE[, PASSES]>: AMODE 1 is the implicit 3x3 convolution
+        amode = args[6].strip() if len(args) > 6 else "0"
+        return "gemm_fh2_kernel<1>" if amode == "1" else "gemm_fh2_kernel"
     for k, v in KEYS.items():
         if k in n:
             return v
